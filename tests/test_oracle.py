@@ -1,0 +1,123 @@
+"""CPU: pin the oracle restatement (oracle/ref_torch.py) against golden vectors produced by the
+REAL reference modules (oracle/make_golden.py).  Tolerances: fp32 round-off only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from oracle import weights as W
+from oracle.make_golden import CASES, case_inputs, noise_list
+
+RTOL = 2e-5   # oracle vs real reference: same ATen ops, differences are summation-order noise
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    for name, (kw, *_r) in CASES.items():
+        spec = W.unet1d_param_spec(**kw)
+        assert {k: list(s) for k, s in spec.items()} == {k: s for k, s in keys[name]}, name   # order-free
+
+
+def test_param_count():
+    n = sum(int(np.prod(s)) for s in W.unet1d_param_spec(**W.UNCOND_BEDROOM).values())
+    assert n == 77676094           # SURVEY.md 3.4 (probe of the real module)
+    n = sum(int(np.prod(s)) for s in W.unet1d_param_spec(**W.UNCOND_LIVING).values())
+    assert n == 77679169
+
+
+def test_schedule_tables_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule_v_T1000.npz"))
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    for k in g.files:
+        assert np.array_equal(tb[k].numpy(), g[k]), k
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_unet_forward_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "unet_forward.npz"))
+    kw, x, t, cond, cross = case_inputs(name)
+    sd = W.synth_state_dict(kw)
+    with torch.no_grad():
+        out = R.unet1d_forward(sd, kw, x, t, cond, cross)
+    assert out.shape == g[name].shape
+    assert _rel(out, g[name]) < RTOL
+
+
+@pytest.mark.parametrize("name", ["uncond_bedroom", "uncond_living"])
+def test_p_losses_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "p_losses.npz"))
+    kw, x, t, cond, cross = case_inputs(name)
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    with torch.no_grad():
+        lw, scal, _ = R.p_losses(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, cross), x, t, noise,
+                                 R.dims_from_kwargs(kw), loss_separate=True, loss_iou=True, stats=W.DATASET_STATS)
+    assert _rel(lw, g[name + ".losses"]) < RTOL
+    for k, v in scal.items():
+        ref = float(g[name + "." + k])
+        assert abs(float(v) - ref) <= RTOL * max(1.0, abs(ref)), k
+
+
+def test_reverse_chain_T50_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 50, "v")
+    den = lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None)
+    with torch.no_grad():
+        s = R.p_sample_loop(tb, den, (B, N, C), noise_list([(B, N, C)] * 51, 1, "chain50_"), 50, True)
+        assert _rel(s, g["uncond_T50"]) < 1e-4
+        s = R.p_sample_loop(tb, den, (B, N, C), noise_list([(B, N, C)] * 51, 3, "noclip_"), 50, False)
+        assert _rel(s, g["uncond_noclip_T50"]) < 1e-4
+        shapes = [(B, N, C)]
+        for _ in range(50):
+            shapes += [(B, 3, C), (B, N, C)]
+        s = R.p_sample_loop_complete(tb, den, (B, N, C), noise_list(shapes, 2, "complete_"), 50,
+                                     x[:, :3, :].contiguous(), True)
+        assert _rel(s, g["complete_T50"]) < 1e-4
+
+
+def test_text_and_arrange_chains_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, cross = case_inputs("text_bedroom")
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 20, "v")
+    with torch.no_grad():
+        s = R.p_sample_loop(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, cross), tuple(x.shape),
+                            noise_list([tuple(x.shape)] * 21, 4, "text_"), 20, True)
+    assert _rel(s, g["text_T20"]) < 1e-4
+    kw, x, t, cond, _ = case_inputs("rearrange_living")
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 50, "v")
+    B, N = x.shape[:2]
+    full = W.synth_scene_batch(B, N, 25, 32, 5)
+    with torch.no_grad():
+        s = R.p_sample_loop_arrange(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None), (B, N, 65),
+                                    noise_list([(B, N, 5)] * 51, 5, "arrange_"), 50, full,
+                                    dict(translation_dim=3, size_dim=3, bbox_dim=8), True)
+    assert s.shape == g["arrange_T50"].shape
+    assert _rel(s, g["arrange_T50"]) < 1e-4
+
+
+def test_reverse_chain_T1000_matches_reference(golden_dir):
+    """Full-length chain (B=1, N=12): the restatement must stay within 1e-4 relative of the real
+    reference over 1000 dependent steps (SURVEY.md 8c noise floor: 1.3e-6)."""
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    _, N, C = x.shape
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    with torch.no_grad():
+        s = R.p_sample_loop(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond[:1], None), (1, N, C),
+                            noise_list([(1, N, C)] * 1001, 1, "chain1000_"), 1000, True)
+    assert _rel(s, g["uncond_T1000"]) < 1e-4
