@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""Benchmark of the DiffuScene DDPM hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W [--mode sample|train] [--batch 256] [--objects 80]
+
+Workload (BASELINE.json `metric`): uncond living/dining rooms scaled to N=80 objects, B=256 scenes per GPU,
+C=65 channels, fp32, synthetic scenes with the real encoders' value distribution, random-init weights.
+  mode=sample : a step = one reverse-diffusion denoiser step (Unet1D forward + fused posterior step) of a
+                1000-step p_sample_loop, replayed from the captured hipGraph.
+  mode=train  : a step = train_on_batch semantics (q_sample, forward, loss incl. IoU, backward, clip(10), Adam).
+N > 1: one process per GPU (torchrun), batch sharded by rank (weak scaling: per-GPU batch fixed); sampling
+needs no collective, training all-reduces the gradients over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def unet_forward_flops(B, N):
+    """F(B,N) = B*N*(65.01e6 + 512*N) + B*90.2e6 (uncond, C=62/65)."""
+    return B * N * (65.01e6 + 512.0 * N) + B * 90.2e6
+
+
+def build_model(args, device):
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    from oracle import weights as W
+    import tempfile
+    stats = os.path.join(tempfile.mkdtemp(), "dataset_stats.txt")
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    kw = dict(W.UNCOND_LIVING)
+    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 65, "latent_dim": 0,
+           "room_mask_condition": False, "sample_num_points": args.objects, "objectness_dim": 0, "objfeat_dim": 32,
+           "class_dim": 25, "angle_dim": 2, "learnable_embedding": True, "instance_condition": True,
+           "instance_emb_dim": 128,
+           "diffusion_kwargs": dict(schedule_type="linear", beta_start=1e-4, beta_end=0.02, time_num=1000,
+                                    loss_type="mse", model_mean_type="v", model_var_type="fixedsmall",
+                                    loss_separate=True, loss_iou=True, train_stats_file=stats),
+           "net_kwargs": kw}
+    torch.manual_seed(0)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = DiffusionSceneLayout_DDPM(26, None, cfg)
+    return model.to(device), cfg
+
+
+def barrier(ws):
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def bench_sample(args, model, device, ws):
+    from diffuscene_amd.sampler import _StepGraph
+    B, N, C = args.batch, args.objects, 65
+    diff = model.diffusion.diffusion
+    cond = model._instance_condition(B, device)
+    with torch.no_grad():
+        g = _StepGraph(diff, model.diffusion.model, (B, N, C), device, cond, None, True)
+        g.x.normal_()
+        g.t.fill_(999)
+        for _ in range(args.warmup):
+            g.graph.replay()
+        g.t.fill_(999)
+        barrier(ws)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.graph.replay()
+        barrier(ws)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(g.x).all()
+    return dt, g
+
+
+def bench_train(args, model, cfg, device, ws):
+    from diffuscene_amd.networks import optimizer_factory
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import train_on_batch
+    from oracle import weights as W
+    B, N = args.batch, args.objects
+    rank = dist.get_rank() if ws > 1 else 0
+    x = W.synth_scene_batch(B, N, 25, 32, seed=100 + rank).to(device)
+    sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
+              "angles": x[:, :, 6:8].contiguous(), "class_labels": x[:, :, 8:33].contiguous(),
+              "objfeats_32": x[:, :, 33:65].contiguous(), "room_layout": torch.zeros(B, 1, 64, 64, device=device)}
+    opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4}, filter(lambda p: p.requires_grad, model.parameters()))
+    tcfg = {"training": {"max_grad_norm": 10}}
+    for _ in range(args.warmup):
+        train_on_batch(model, opt, sample, tcfg)
+    barrier(ws)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_on_batch(model, opt, sample, tcfg)
+    barrier(ws)
+    return time.perf_counter() - t0
+
+
+def roofline_dominant_kernel(plan, B, N):
+    """Time the dominant kernel -- the fused WS-conv + GroupNorm + SiLU GEMM (gemm_kernel<...,GN=true>, K=512) --
+    with HIP events on the launch stream, using the very argument structs of the timed plan."""
+    import ctypes as C
+    from diffuscene_amd import _lib, ops
+    fn = _lib.fn("dsc_gemm_gn_silu_f32")
+    steps = [a for f, a in plan.steps if f is fn]
+    structs = [a[0]._obj for a in steps]          # ctypes.byref(struct) keeps the struct in ._obj
+    sel = [(a, s) for a, s in zip(steps, structs) if s.k1 + s.k2 == 512]
+    s = ops.stream_ptr()
+    for a, _ in sel[:4]:
+        fn(*a, s)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    ev0.record()
+    for _ in range(reps):
+        for a, _ in sel:
+            fn(*a, s)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / (reps * len(sel))
+    flops = 2.0 * B * N * 512 * 512
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512)" % (B * N),
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
+            "launches_per_step": len(steps), "traffic": None}
+
+
+def cpu_baseline(args, mode):
+    """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores on a bounded
+    sample: a few steps on a slice of the batch, scaled linearly to the full batch (scenes are independent)."""
+    from oracle import ref_torch as R
+    from oracle import weights as W
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    kw = dict(W.UNCOND_LIVING)
+    sd = W.synth_state_dict(kw)
+    Bs, N = min(args.batch, 16), args.objects
+    x = W.synth_scene_batch(Bs, N, 25, 32, seed=0)
+    cond = W.synth_condition(Bs, N, 128, 0).contiguous()
+    t = torch.full((Bs,), 500, dtype=torch.int64)
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    noise = torch.randn(Bs, N, 65)
+
+    def one_sample_step():
+        with torch.no_grad():
+            out = R.unet1d_forward(sd, kw, x, t, cond, None)
+            return R.p_sample_step(tb, x, t, out, noise, True, "v")
+
+    def one_train_step():
+        params = [p.requires_grad_(True) for p in sd.values()]
+        lw, _, _ = R.p_losses(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None), x, t, noise,
+                              R.dims_from_kwargs(kw), True, True, W.DATASET_STATS)
+        lw.mean().backward()
+        for p in params:
+            p.grad = None
+
+    fn = one_sample_step if mode == "sample" else one_train_step
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 20:
+            break
+    per_full = (el / n) * (args.batch / Bs)
+    return {"value": round(1.0 / per_full, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d %s steps of the oracle on %d of %d scenes (N=%d), scaled x%d to the full batch%s"
+                      % (n, mode, Bs, args.batch, N, args.batch // Bs,
+                         "" if mode == "sample" else " (fwd+bwd only, no optimizer)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default=os.environ.get("DSC_BENCH_MODE", "sample"), choices=["sample", "train"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--objects", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if ws > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    rank = dist.get_rank() if ws > 1 else 0
+    assert ws == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, ws)
+
+    model, cfg = build_model(args, device)
+    plan = None
+    if args.mode == "sample":
+        dt, g = bench_sample(args, model, device, ws)
+        plan = g.plan
+    else:
+        dt = bench_train(args, model, cfg, device, ws)
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if ws > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        B, N = args.batch, args.objects
+        steps_per_s = args.steps * ws / dt        # whole job: every rank advances its own B scenes one step
+        out = {
+            "metric": "denoiser steps/sec (%s) at B=256, N=80 objects" % (
+                "1000-step sample loop" if args.mode == "sample" else "train step"),
+            "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": ws, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "uncond living/dining rooms (config/uncond/diffusion_livingrooms_instancond_lat32_v.yaml "
+                                   "scaled to N=%d), B=%d scenes per GPU, C=65, T=1000, mode=%s" % (N, B, args.mode),
+                       "global_batch": B * ws, "parallelism": "dp%d" % ws if ws > 1 else "single"},
+        }
+        F = unet_forward_flops(B, N)
+        mult = 1.0 if args.mode == "sample" else 3.0
+        out["model_tflops"] = round(mult * F * args.steps / dt / 1e12, 2)        # per GPU, algorithmic
+        out["model_frac_of_fp32_mfma_peak"] = round(out["model_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        if plan is None:
+            with torch.no_grad():
+                plan = model.diffusion.model.engine(device).prepare(B, N, model._instance_condition(B, device), None)
+                plan.x_in.normal_(); plan.t_in.fill_(500); plan.run()
+        out["roofline"] = roofline_dominant_kernel(plan, B, N)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.mode)
+        print(json.dumps(out))
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

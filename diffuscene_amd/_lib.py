@@ -1,0 +1,107 @@
+"""ctypes binding of libdiffuscene_hip.so (C ABI declared in include/diffuscene_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).  There is no
+fallback: if the shared object is missing, ``load()`` raises, and every op in this package goes through it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiffuscene_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT = 0, 1, 2, 3
+MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
+WS_MAX = 64
+MAX_TOKENS_PER_SCENE = 160
+
+_ERR = {-1: "DSC_EINVAL (bad shape / null pointer)", -2: "DSC_EALIGN (16-byte alignment required)",
+        -3: "DSC_ERANGE (size outside kernel limits)"}
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a1", C.c_void_p), ("lda1", C.c_int64), ("k1", C.c_int32),
+        ("a2", C.c_void_p), ("lda2", C.c_int64), ("k2", C.c_int32),
+        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("y", C.c_void_p), ("ldy", C.c_int64),
+        ("m", C.c_int32), ("n", C.c_int32),
+        ("act_in", C.c_int32), ("act_out", C.c_int32),
+        ("batch", C.c_int32),
+        ("sa1", C.c_int64), ("sa2", C.c_int64), ("sw", C.c_int64), ("sbias", C.c_int64),
+        ("sres", C.c_int64), ("sy", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+        ("tokens_per_scene", C.c_int32),
+        ("scale_shift", C.c_void_p), ("ld_ss", C.c_int64), ("ss_mode", C.c_int32),
+    ]
+
+
+class WsItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+# name -> (restype, argtypes); must list every function declared in include/diffuscene_hip.h
+SIGNATURES = {
+    "dsc_version": (C.c_int, []),
+    "dsc_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "dsc_gemm_gn_silu_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "dsc_linear_smallk_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dsc_weight_standardize_f32": (C.c_int, [C.POINTER(WsItem), C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_layernorm_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
+                                    C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_linear_attention_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_attention_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64,
+                                    C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_time_embedding_f32": (C.c_int, [c_i64p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    "dsc_activation_f32": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dsc_q_sample_f32": (C.c_int, [c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int64,
+                                   C.c_void_p]),
+    "dsc_p_sample_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                   c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "dsc_add_scalar_i64": (C.c_int, [c_i64p, C.c_int32, C.c_int64, C.c_void_p]),
+    "dsc_complete_overwrite_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "diffuscene_amd has no CPU or PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryMissing("symbol %s missing from %s" % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))
+
+
+def fn(name):
+    return getattr(load(), name)

@@ -1,0 +1,412 @@
+// Non-GEMM denoiser kernels: weight standardisation, channel LayerNorm, linear / softmax attention cores,
+// small-K input projection, time embedding, activation.  All HBM- or latency-bound; one pass over the data,
+// wave-level shuffles for the reductions, K/V tiles of one scene staged in LDS.
+#include "dsc_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// WeightStandardizedConv2d weight path (denoise_net.py:84-89): one 256-thread block per weight row.
+// ------------------------------------------------------------------------------------------------
+struct WsBatch { dsc_ws_item it[DSC_WS_MAX]; };
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void ws_kernel(const WsBatch b, const float eps) {
+    __shared__ float red[4];
+    const dsc_ws_item it = b.it[blockIdx.y];
+    const int row = blockIdx.x;
+    if (row >= it.rows) return;
+    const float* w = it.w + (int64_t)row * it.cols;
+    float* o = it.out + (int64_t)row * it.cols;
+    constexpr int MAXE = 8;   // cols <= 2048
+    float v[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = (c < it.cols) ? w[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = block_sum_256(s, red) / (float)it.cols;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        const float d = (c < it.cols) ? v[i] - mean : 0.f;
+        s2 += d * d;
+    }
+    const float var = block_sum_256(s2, red) / (float)it.cols;
+    const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < it.cols) o[c] = (v[i] - mean) * rs;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// channel LayerNorm with gain (+ residual), d = 512: one wave per token row, 8 floats per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ g,
+                                                          const float* __restrict__ res, int64_t ldr,
+                                                          float* __restrict__ y, int64_t ldy, int m, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xr + lane * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 256 + lane * 4);
+    float s = (a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]);
+    const float mean = wave_sum(s) * (1.0f / 512.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float da = a[e] - mean, db = b[e] - mean;
+        s2 += da * da + db * db;
+    }
+    const float var = wave_sum(s2) * (1.0f / 512.0f);
+    const float rs = 1.0f / sqrtf(var + eps);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(g + lane * 4);
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(g + 256 + lane * 4);
+    f32x4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        oa[e] = (a[e] - mean) * rs * ga[e];
+        ob[e] = (b[e] - mean) * rs * gb[e];
+    }
+    if (res) {
+        const float* rr = res + (int64_t)row * ldr;
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(rr + lane * 4);
+        const f32x4 rb = *reinterpret_cast<const f32x4*>(rr + 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { oa[e] += ra[e]; ob[e] += rb[e]; }
+    }
+    float* yr = y + (int64_t)row * ldy;
+    *reinterpret_cast<f32x4*>(yr + lane * 4) = oa;
+    *reinterpret_cast<f32x4*>(yr + 256 + lane * 4) = ob;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear attention core, one 128-thread block per (scene, head); K/V head slices of the scene in LDS.
+//   LDS rows padded to 33 floats: column walks (softmax over tokens) are conflict-free.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXTOK = 160;
+constexpr int HP = 33;
+
+__global__ __launch_bounds__(128) void linear_attention_kernel(const float* __restrict__ q, int64_t ldq,
+                                                               const float* __restrict__ k, int64_t ldk,
+                                                               const float* __restrict__ v, int64_t ldv,
+                                                               float* __restrict__ out, int64_t ldo,
+                                                               int nq, int nk, float scale) {
+    __shared__ float Ks[MAXTOK * HP];
+    __shared__ float Vs[MAXTOK * HP];
+    __shared__ float ctx[32 * HP];
+    __shared__ float cmax[32], cinv[32];
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int tid = threadIdx.x;
+    const float* kb = k + (int64_t)b * nk * ldk + h * 32;
+    const float* vb = v + (int64_t)b * nk * ldv + h * 32;
+    // stage K and V (nk x 32 each): float4 per thread-iteration, 8 threads per token row
+    for (int f = tid; f < nk * 8; f += 128) {
+        const int j = f >> 3, c4 = (f & 7) * 4;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { Ks[j * HP + c4 + e] = kv[e]; Vs[j * HP + c4 + e] = vv[e]; }
+    }
+    __syncthreads();
+    // softmax of k over the nk tokens, per head channel d: 4 threads per channel
+    {
+        const int d = tid >> 2, part = tid & 3;
+        float mx = -INFINITY;
+        for (int j = part; j < nk; j += 4) mx = fmaxf(mx, Ks[j * HP + d]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sm = 0.f;
+        for (int j = part; j < nk; j += 4) {
+            const float e = expf(Ks[j * HP + d] - mx);
+            Ks[j * HP + d] = e;
+            sm += e;
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        if (part == 0) { cmax[d] = mx; cinv[d] = 1.0f / sm; }
+    }
+    __syncthreads();
+    // context[d][e] = sum_j softk[j][d] v[j][e]; thread -> (d, 8 consecutive e)
+    {
+        const int d = tid >> 2, e0 = (tid & 3) * 8;
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            const float kd = Ks[j * HP + d];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += kd * Vs[j * HP + e0 + e];
+        }
+        const float inv = cinv[d];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ctx[d * HP + e0 + e] = a[e] * inv;
+    }
+    __syncthreads();
+    // per query token: softmax over the 32 head channels, * scale, then out[e] = sum_d ctx[d][e] q[d]
+    for (int i = tid; i < nq; i += 128) {
+        const float* qr = q + ((int64_t)b * nq + i) * ldq + h * 32;
+        float qv[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(qr + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[c * 4 + e] = t4[e];
+        }
+        float mx = qv[0];
+#pragma unroll
+        for (int d = 1; d < 32; ++d) mx = fmaxf(mx, qv[d]);
+        float sm = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qv[d] = expf(qv[d] - mx); sm += qv[d]; }
+        const float inv = 1.0f / sm;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) qv[d] = qv[d] * inv * scale;
+        float o[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            const float qd = qv[d];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) o[e] += ctx[d * HP + e] * qd;
+        }
+        float* orow = out + ((int64_t)b * nq + i) * ldo + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 t4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t4[e] = o[c * 4 + e];
+            *reinterpret_cast<f32x4*>(orow + c * 4) = t4;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Softmax attention core (mid_attn), one block per (scene, head), one thread per query token.
+// K/V of the scene in LDS (broadcast reads: every lane walks the same key), two passes over the keys
+// (row max, then exp / sum / PV) so the result is the plain softmax of the reference.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void attention_kernel(const float* __restrict__ q, int64_t ldq,
+                                                        const float* __restrict__ k, int64_t ldk,
+                                                        const float* __restrict__ v, int64_t ldv,
+                                                        float* __restrict__ out, int64_t ldo, int n, float scale) {
+    __shared__ float Ks[MAXTOK * HP];
+    __shared__ float Vs[MAXTOK * HP];
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int tid = threadIdx.x;
+    const float* kb = k + (int64_t)b * n * ldk + h * 32;
+    const float* vb = v + (int64_t)b * n * ldv + h * 32;
+    for (int f = tid; f < n * 8; f += 192) {
+        const int j = f >> 3, c4 = (f & 7) * 4;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { Ks[j * HP + c4 + e] = kv[e]; Vs[j * HP + c4 + e] = vv[e]; }
+    }
+    __syncthreads();
+    const int i = tid;
+    if (i >= n) return;
+    const float* qr = q + ((int64_t)b * n + i) * ldq + h * 32;
+    float qv[32];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(qr + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[c * 4 + e] = t4[e] * scale;
+    }
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s += qv[d] * Ks[j * HP + d];
+        mx = fmaxf(mx, s);
+    }
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    float sm = 0.f;
+    for (int j = 0; j < n; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s += qv[d] * Ks[j * HP + d];
+        const float pj = expf(s - mx);
+        sm += pj;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] += pj * Vs[j * HP + d];
+    }
+    const float inv = 1.0f / sm;
+    float* orow = out + ((int64_t)b * n + i) * ldo + h * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        f32x4 t4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[e] = o[c * 4 + e] * inv;
+        *reinterpret_cast<f32x4*>(orow + c * 4) = t4;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small-K linear on un-aligned rows: 32 tokens per block staged in LDS as [k][token]; thread = channel.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_TOK = 32;
+constexpr int SK_MAXK = 64;
+
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ x, int64_t ldx, int kin,
+                                                            const float* __restrict__ w, int64_t ldw,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ y, int64_t ldy, int m, int n, int act) {
+    __shared__ float xs[SK_MAXK * SK_TOK];
+    const int tok0 = blockIdx.x * SK_TOK;
+    const int ntok = (m - tok0) < SK_TOK ? (m - tok0) : SK_TOK;
+    for (int f = threadIdx.x; f < SK_TOK * kin; f += 256) {
+        const int t = f / kin, kk = f - t * kin;
+        xs[kk * SK_TOK + t] = (t < ntok) ? x[(int64_t)(tok0 + t) * ldx + kk] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += 256) {
+        float acc[SK_TOK];
+        const float b = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < SK_TOK; ++t) acc[t] = b;
+        const float* wr = w + (int64_t)c * ldw;
+        for (int kk = 0; kk < kin; ++kk) {
+            const float wv = wr[kk];
+#pragma unroll
+            for (int t4 = 0; t4 < SK_TOK / 4; ++t4) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[kk * SK_TOK + t4 * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t4 * 4 + e] += wv * xv[e];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SK_TOK; ++t)
+            if (t < ntok) y[(int64_t)(tok0 + t) * ldy + c] = dsc_act(acc[t], act);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void time_embedding_kernel(const int64_t* __restrict__ t, int b, int dim, const float* __restrict__ table,
+                                      int table_rows, const float* __restrict__ freq, float* __restrict__ out) {
+    const int row = blockIdx.x;
+    if (row >= b) return;
+    const int64_t tv = t[row];
+    const int half = dim >> 1;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        float o;
+        if (table && tv >= 0 && tv < table_rows) o = table[tv * dim + c];
+        else {
+            const float a = (float)tv * freq[c < half ? c : c - half];
+            o = c < half ? sinf(a) : cosf(a);
+        }
+        out[(int64_t)row * dim + c] = o;
+    }
+}
+
+__global__ void activation_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count, int act) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) y[i] = dsc_act(x[i], act);
+}
+
+}  // namespace
+
+extern "C" int dsc_version(void) { return 100; }
+
+extern "C" int dsc_weight_standardize_f32(const dsc_ws_item* items, int32_t count, float eps, dsc_stream_t stream) {
+    if (!items || count < 1 || count > DSC_WS_MAX) return DSC_EINVAL;
+    WsBatch b;
+    int maxrows = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].w || !items[i].out || items[i].rows < 1 || items[i].cols < 1) return DSC_EINVAL;
+        if (items[i].cols > 2048) return DSC_ERANGE;
+        b.it[i] = items[i];
+        if (items[i].rows > maxrows) maxrows = items[i].rows;
+    }
+    hipLaunchKernelGGL(ws_kernel, dim3(maxrows, count), dim3(256), 0, static_cast<hipStream_t>(stream), b, eps);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_layernorm_f32(const float* x, int64_t ldx, const float* g, const float* residual, int64_t ldr,
+                                 float* y, int64_t ldy, int32_t m, int32_t d, float eps, dsc_stream_t stream) {
+    if (!x || !g || !y || m < 1) return DSC_EINVAL;
+    if (d != 512) return DSC_ERANGE;
+    if (!dsc_aligned16(x) || !dsc_aligned16(g) || !dsc_aligned16(y) || (ldx & 3) || (ldy & 3)) return DSC_EALIGN;
+    if (residual && (!dsc_aligned16(residual) || (ldr & 3))) return DSC_EALIGN;
+    hipLaunchKernelGGL(layernorm512_kernel, dim3((m + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, ldx, g, residual, ldr, y, ldy, m, eps);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_linear_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                                        const float* v, int64_t ldv, float* out, int64_t ldo,
+                                        int32_t scenes, int32_t nq, int32_t nk, float scale, dsc_stream_t stream) {
+    if (!q || !k || !v || !out || scenes < 1 || nq < 1 || nk < 1) return DSC_EINVAL;
+    if (nk > MAXTOK) return DSC_ERANGE;
+    if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(out) ||
+        (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DSC_EALIGN;
+    hipLaunchKernelGGL(linear_attention_kernel, dim3(scenes * DSC_HEADS), dim3(128), 0,
+                       static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, nq, nk, scale);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                                 const float* v, int64_t ldv, float* out, int64_t ldo,
+                                 int32_t scenes, int32_t n, float scale, dsc_stream_t stream) {
+    if (!q || !k || !v || !out || scenes < 1 || n < 1) return DSC_EINVAL;
+    if (n > MAXTOK) return DSC_ERANGE;
+    if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(out) ||
+        (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DSC_EALIGN;
+    hipLaunchKernelGGL(attention_kernel, dim3(scenes * DSC_HEADS), dim3(192), 0,
+                       static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, n, scale);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_linear_smallk_f32(const float* x, int64_t ldx, int32_t k_in, const float* w, int64_t ldw,
+                                     const float* bias, float* y, int64_t ldy, int32_t m, int32_t n,
+                                     int32_t act_out, dsc_stream_t stream) {
+    if (!x || !w || !y || m < 1 || n < 1 || k_in < 1) return DSC_EINVAL;
+    if (k_in > SK_MAXK) return DSC_ERANGE;
+    hipLaunchKernelGGL(linear_smallk_kernel, dim3((m + SK_TOK - 1) / SK_TOK), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, k_in, w, ldw, bias, y, ldy, m, n, act_out);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_time_embedding_f32(const int64_t* t, int32_t b, int32_t dim, const float* table, int32_t table_rows,
+                                      const float* freq, float* out, dsc_stream_t stream) {
+    if (!t || !freq || !out || b < 1 || dim < 2 || (dim & 1)) return DSC_EINVAL;
+    hipLaunchKernelGGL(time_embedding_kernel, dim3(b), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       t, b, dim, table, table_rows, freq, out);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_activation_f32(const float* x, float* y, int64_t count, int32_t act, dsc_stream_t stream) {
+    if (!x || !y || count < 1) return DSC_EINVAL;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, y, count, act);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,121 @@
+// Elementwise DDPM steps (diffusion_ddpm.py:217-352,447-476).  HBM-bound: one read of each operand, one
+// write of the result, coefficient gathers from device-resident tables.  Compiled with -ffp-contract=off:
+// the reference evaluates  a*x + b*y  as two rounded products and a rounded sum; we do exactly that, so the
+// results are bit-identical to the fp32 CPU path on the same inputs.
+#include "dsc_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                      const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                                      const float* __restrict__ sb, float* __restrict__ xt,
+                                                      float* __restrict__ vout, int64_t inner) {
+    const int b = blockIdx.y;
+    const int64_t tv = t[b];
+    const float a = sa[tv], s = sb[tv];
+    const int64_t base = (int64_t)b * inner;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = x0[base + i], n = noise[base + i];
+        const float p0 = a * x, p1 = s * n;
+        xt[base + i] = p0 + p1;
+        if (vout) {
+            const float q0 = a * n, q1 = s * x;
+            vout[base + i] = q0 - q1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void p_sample_kernel(const float* xt, const float* __restrict__ mo,
+                                                      const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                      const float* __restrict__ ca, const float* __restrict__ cb,
+                                                      const float* __restrict__ c1, const float* __restrict__ c2,
+                                                      const float* __restrict__ sigma, float* out,   // out may alias xt (in-place step)
+                                                      float* __restrict__ x0_out, int mean_type, int clip, int64_t inner) {
+    const int b = blockIdx.y;
+    const int64_t tv = t[b];
+    const float A = (mean_type == DSC_MEAN_X0) ? 0.f : ca[tv];
+    const float Bc = (mean_type == DSC_MEAN_X0) ? 0.f : cb[tv];
+    const float k1 = c1[tv], k2 = c2[tv];
+    const float sg = (tv != 0) ? sigma[tv] : 0.f;
+    const int64_t base = (int64_t)b * inner;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = xt[base + i], m = mo[base + i];
+        float x0;
+        if (mean_type == DSC_MEAN_X0) x0 = m;
+        else { const float p0 = A * x, p1 = Bc * m; x0 = p0 - p1; }
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const float m0 = k1 * x0, m1 = k2 * x;
+        const float mean = m0 + m1;
+        const float nz = sg * noise[base + i];
+        out[base + i] = mean + nz;
+        if (x0_out) x0_out[base + i] = x0;
+    }
+}
+
+__global__ void add_scalar_i64_kernel(int64_t* t, int count, int64_t delta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) t[i] += delta;
+}
+
+__global__ __launch_bounds__(256) void complete_overwrite_kernel(float* __restrict__ x, const float* __restrict__ partial,
+                                                                const float* __restrict__ noise,
+                                                                const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                                                const float* __restrict__ sb, int n, int p, int c) {
+    const int b = blockIdx.y;
+    const int64_t tv = t[b];
+    const float a = sa[tv], s = sb[tv];
+    const int64_t cnt = (int64_t)p * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p0 = a * partial[(int64_t)b * cnt + i], p1 = s * noise[(int64_t)b * cnt + i];
+        x[(int64_t)b * n * c + i] = p0 + p1;   // rows [0,p) of scene b are the first p*c elements
+    }
+}
+
+inline unsigned grid_x(int64_t inner) {
+    int64_t g = (inner + 255) / 256;
+    return (unsigned)(g > 64 ? 64 : g);
+}
+
+}  // namespace
+
+extern "C" int dsc_q_sample_f32(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
+                                const float* sqrt_1mac, float* x_t, float* v_out, int32_t b, int64_t inner,
+                                dsc_stream_t stream) {
+    if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t || b < 1 || inner < 1) return DSC_EINVAL;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_x(inner), b), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x0, noise, t, sqrt_ac, sqrt_1mac, x_t, v_out, inner);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_p_sample_f32(const float* x_t, const float* model_out, const float* noise, const int64_t* t,
+                                const float* ca, const float* cb, const float* coef1, const float* coef2,
+                                const float* sigma, float* out, float* x0_out, int32_t mean_type, int32_t clip,
+                                int32_t b, int64_t inner, dsc_stream_t stream) {
+    if (!x_t || !model_out || !noise || !t || !coef1 || !coef2 || !sigma || !out || b < 1 || inner < 1) return DSC_EINVAL;
+    if (mean_type < DSC_MEAN_EPS || mean_type > DSC_MEAN_V) return DSC_EINVAL;
+    if (mean_type != DSC_MEAN_X0 && (!ca || !cb)) return DSC_EINVAL;
+    hipLaunchKernelGGL(p_sample_kernel, dim3(grid_x(inner), b), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x_t, model_out, noise, t, ca, cb, coef1, coef2, sigma, out, x0_out, mean_type, clip, inner);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t stream) {
+    if (!t || count < 1) return DSC_EINVAL;
+    hipLaunchKernelGGL(add_scalar_i64_kernel, dim3((count + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), t, count, delta);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_complete_overwrite_f32(float* x, const float* partial, const float* noise, const int64_t* t,
+                                          const float* sqrt_ac, const float* sqrt_1mac, int32_t b, int32_t n,
+                                          int32_t p, int32_t c, dsc_stream_t stream) {
+    if (!x || !partial || !noise || !t || !sqrt_ac || !sqrt_1mac || b < 1 || n < 1 || p < 1 || p > n || c < 1)
+        return DSC_EINVAL;
+    hipLaunchKernelGGL(complete_overwrite_kernel, dim3(grid_x((int64_t)p * c), b), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, partial, noise, t, sqrt_ac, sqrt_1mac, n, p, c);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,40 @@
+// Shared device helpers for libdiffuscene_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/diffuscene_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DSC_WAVE 64
+
+#define DSC_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+__device__ __forceinline__ float dsc_silu(float x) { return x / (1.0f + expf(-x)); }
+// nn.GELU() default: 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float dsc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float dsc_act(float x, int act) {
+    if (act == DSC_ACT_GELU) return dsc_gelu(x);
+    if (act == DSC_ACT_SILU) return dsc_silu(x);
+    return x;
+}
+
+// butterfly reductions over the 64 lanes of a wave
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline bool dsc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,305 @@
+"""Scene-layout wrapper around the DDPM -- drop-in for
+scene_synthesis/networks/diffusion_scene_layout_ddpm.py (``DiffusionSceneLayout_DDPM``, ``train_on_batch``,
+``validate_on_batch``): same constructor, config keys, sample_params keys, method names, state_dict keys
+(``diffusion.model.*``, ``positional_embedding``, ``fc_text_f.*``, ``fc_arrange_condition.*`` ...).
+
+What changed underneath:
+* the instance embedding is broadcast over the batch as a stride-0 view instead of a gathered (B,N,128)
+  copy (:174-175), which lets the denoiser push N instead of B*N rows through its 9 context MLPs;
+* ``train_on_batch`` reads all logged scalars with ONE device->host copy instead of 11 ``.item()`` syncs
+  (:461-473), and all-reduces gradients over RCCL when torch.distributed is initialised (data parallel);
+* post-filtering of empty boxes (:351-406) is vectorised; it still looks only at batch row 0, as the reference.
+Optional third-party encoders (BERT / CLIP / floor-plan ResNet) are imported only when the config asks for them.
+"""
+import torch
+import torch.nn as nn
+from torch.nn import Module
+
+from ..stats_logger import StatsLogger
+from .denoise_net import Unet1D
+from .diffusion_ddpm import DiffusionPoint
+
+
+def _two_layer(n_in, n_out):
+    return nn.Sequential(nn.Linear(n_in, n_out, bias=False), nn.LeakyReLU(0.1, inplace=True),
+                         nn.Linear(n_out, n_out, bias=False))
+
+
+class DiffusionSceneLayout_DDPM(Module):
+
+    def __init__(self, n_classes, feature_extractor, config):
+        super().__init__()
+        self.room_mask_condition = config.get("room_mask_condition", True)
+        self.text_condition = config.get("text_condition", False)
+        self.text_glove_embedding = config.get("text_glove_embedding", False)
+        self.text_clip_embedding = config.get("text_clip_embedding", False)
+        if self.room_mask_condition:
+            self.feature_extractor = feature_extractor
+            self.fc_room_f = nn.Linear(self.feature_extractor.feature_size, config["latent_dim"])
+            print('use room mask as condition')
+        elif self.text_condition:
+            text_embed_dim = config.get("text_embed_dim", 512)
+            if self.text_glove_embedding:
+                self.fc_text_f = nn.Linear(50, text_embed_dim)
+                print('use text as condition, and pretrained glove embedding')
+            elif self.text_clip_embedding:
+                import clip
+                device = "cuda" if torch.cuda.is_available() else "cpu"
+                self.clip_model, self.clip_preprocess = clip.load("ViT-B/32", device=device)
+                for p in self.clip_model.parameters():
+                    p.requires_grad = False
+                print('use text as condition, and pretrained clip embedding')
+            else:
+                from transformers import BertModel, BertTokenizer
+                self.tokenizer = BertTokenizer.from_pretrained('bert-base-cased')
+                self.bertmodel = BertModel.from_pretrained("bert-base-cased")
+                for p in self.bertmodel.parameters():
+                    p.requires_grad = False
+                self.fc_text_f = nn.Linear(768, text_embed_dim)
+                print('use text as condition, and pretrained bert model')
+        else:
+            print('NOT use room and text as condition')
+
+        if config["net_type"] == "unet1d":
+            denoise_net = Unet1D(**config["net_kwargs"])
+        else:
+            raise NotImplementedError()
+        self.diffusion = DiffusionPoint(denoise_net=denoise_net, config=config, **config["diffusion_kwargs"])
+        self.n_classes = n_classes
+        self.config = config
+
+        self.objectness_dim = config.get("objectness_dim", 1)
+        self.class_dim = config.get("class_dim", 21)
+        self.translation_dim = config.get("translation_dim", 3)
+        self.size_dim = config.get("size_dim", 3)
+        self.angle_dim = config.get("angle_dim", 1)
+        self.bbox_dim = self.translation_dim + self.size_dim + self.angle_dim
+        self.objfeat_dim = config.get("objfeat_dim", 0)
+
+        self.learnable_embedding = config.get("learnable_embedding", False)
+        self.instance_condition = config.get("instance_condition", False)
+        self.sample_num_points = config.get("sample_num_points", 12)
+        self.instance_emb_dim = config.get("instance_emb_dim", 64)
+        if self.learnable_embedding:
+            if self.instance_condition:
+                self.register_parameter("positional_embedding",
+                                        nn.Parameter(torch.randn(self.sample_num_points, self.instance_emb_dim)))
+            else:
+                self.instance_emb_dim = 0
+        else:
+            if self.instance_condition:
+                self.fc_instance_condition = _two_layer(self.sample_num_points, self.instance_emb_dim)
+            else:
+                self.instance_emb_dim = 0
+
+        self.room_partial_condition = config.get("room_partial_condition", False)
+        self.partial_num_points = config.get("partial_num_points", 0)
+        self.partial_emb_dim = config.get("partial_emb_dim", 64)
+        full = self.bbox_dim + self.class_dim + self.objectness_dim + self.objfeat_dim
+        if self.room_partial_condition:
+            self.fc_partial_condition = _two_layer(full, self.partial_emb_dim)
+        else:
+            self.partial_emb_dim = 0
+        self.room_arrange_condition = config.get("room_arrange_condition", False)
+        self.arrange_emb_dim = config.get("arrange_emb_dim", 64)
+        if self.room_arrange_condition:
+            self.fc_arrange_condition = _two_layer(full - self.translation_dim - self.angle_dim, self.arrange_emb_dim)
+        else:
+            self.arrange_emb_dim = 0
+
+    # ------------------------------------------------------------------------------------ conditions
+    def _instance_condition(self, batch_size, device):
+        if not self.instance_condition:
+            return None
+        if self.learnable_embedding:
+            # same values as positional_embedding[arange(N)].repeat(B, 1, 1) (:174-175), without the copy
+            return self.positional_embedding[None, :, :].expand(batch_size, -1, -1)
+        eye = torch.eye(self.sample_num_points, device=device)
+        return self.fc_instance_condition(eye)[None].expand(batch_size, -1, -1)
+
+    def _base_condition(self, room_mask, batch_size, num_points, device):
+        room_layout_f = self.fc_room_f(self.feature_extractor(room_mask)) if self.room_mask_condition else None
+        inst = self._instance_condition(batch_size, device)
+        if room_layout_f is not None and inst is not None:
+            return torch.cat([room_layout_f[:, None, :].repeat(1, num_points, 1), inst], dim=-1).contiguous()
+        if room_layout_f is not None:
+            return room_layout_f[:, None, :].repeat(1, num_points, 1)
+        return inst
+
+    def _text_condition(self, text, desc_emb, device):
+        if not self.text_condition:
+            return None
+        if self.text_glove_embedding:
+            return self.fc_text_f(desc_emb)
+        if self.text_clip_embedding:
+            import clip
+            return self.clip_model.encode_text(clip.tokenize(text).to(device))
+        tokenized = self.tokenizer(text, return_tensors='pt', padding=True).to(device)
+        return self.fc_text_f(self.bertmodel(**tokenized).last_hidden_state)
+
+    def _arrange_input(self, boxes):
+        tr, sz, bb = self.translation_dim, self.size_dim, self.bbox_dim
+        return torch.cat([boxes[:, :, tr:tr + sz], boxes[:, :, bb:]], dim=-1).contiguous()
+
+    # ------------------------------------------------------------------------------------ training
+    def get_loss(self, sample_params):
+        """reference :131-226"""
+        class_labels = sample_params["class_labels"]
+        translations, sizes, angles = sample_params["translations"], sample_params["sizes"], sample_params["angles"]
+        batch_size, num_points, _ = class_labels.shape
+        device = class_labels.device
+        full = self.bbox_dim + self.class_dim + self.objectness_dim + self.objfeat_dim
+        if self.config["point_dim"] == full:
+            parts = [translations, sizes, angles, class_labels]
+            if self.objectness_dim > 0:
+                parts.append(sample_params["objectness"])
+            if self.objfeat_dim > 0:
+                parts.append(sample_params["objfeats_32"] if self.objfeat_dim == 32 else sample_params["objfeats"])
+            target = torch.cat(parts, dim=-1).contiguous()
+        elif self.config["point_dim"] == self.bbox_dim:
+            target = torch.cat([translations, sizes, angles], dim=-1).contiguous()
+        else:
+            raise NotImplementedError
+        condition = self._base_condition(sample_params["room_layout"] if self.room_mask_condition else None,
+                                         batch_size, num_points, device)
+        if self.room_partial_condition:
+            mask = torch.zeros((batch_size, num_points, 1), device=device)
+            mask[:, :self.partial_num_points] = 1.0
+            condition = torch.cat([condition, self.fc_partial_condition(target * mask)], dim=-1).contiguous()
+        if self.room_arrange_condition:
+            condition = torch.cat([condition, self.fc_arrange_condition(self._arrange_input(target))],
+                                  dim=-1).contiguous()
+            tr, sz, bb = self.translation_dim, self.size_dim, self.bbox_dim
+            target = torch.cat([target[:, :, 0:tr], target[:, :, tr + sz:bb]], dim=-1).contiguous()
+        condition_cross = self._text_condition(sample_params.get("description"), sample_params.get("desc_emb"), device)
+        return self.diffusion.get_loss_iter(target, condition=condition, condition_cross=condition_cross)
+
+    # ------------------------------------------------------------------------------------ sampling
+    def sample(self, room_mask, num_points, point_dim, batch_size=1, text=None, partial_boxes=None,
+               input_boxes=None, ret_traj=False, ddim=False, clip_denoised=False, freq=40, batch_seeds=None):
+        """reference :228-310"""
+        device = room_mask.device
+        noise = torch.randn((batch_size, num_points, point_dim))   # CPU draw kept: it advances the CPU RNG (:232)
+        condition = self._base_condition(room_mask, room_mask.size(0), num_points, device)
+        if self.room_partial_condition:
+            zeros = torch.zeros((batch_size, num_points - partial_boxes.shape[1], partial_boxes.shape[2]),
+                                device=device)
+            cond_p = self.fc_partial_condition(torch.cat([partial_boxes, zeros], dim=1).contiguous())
+            condition = torch.cat([condition, cond_p], dim=-1).contiguous()
+        if self.room_arrange_condition:
+            condition = torch.cat([condition, self.fc_arrange_condition(self._arrange_input(input_boxes))],
+                                  dim=-1).contiguous()
+        condition_cross = self._text_condition(text, text, device)
+        if self.text_condition and not (self.text_glove_embedding or self.text_clip_embedding):
+            print('after bert:', condition_cross.shape)
+        if input_boxes is not None:
+            print('scene arrangement sampling')
+            return self.diffusion.arrange_samples(noise.shape, device, condition=condition,
+                                                  condition_cross=condition_cross, clip_denoised=clip_denoised,
+                                                  input_boxes=input_boxes)
+        if partial_boxes is not None:
+            print('scene completion sampling')
+            return self.diffusion.complete_samples(noise.shape, device, condition=condition,
+                                                   condition_cross=condition_cross, clip_denoised=clip_denoised,
+                                                   partial_boxes=partial_boxes)
+        print('unconditional / conditional generation sampling')
+        if ret_traj:
+            return self.diffusion.gen_sample_traj(noise.shape, device, freq=freq, condition=condition,
+                                                  condition_cross=condition_cross, clip_denoised=clip_denoised)
+        return self.diffusion.gen_samples(noise.shape, device, condition=condition, condition_cross=condition_cross,
+                                          clip_denoised=clip_denoised)
+
+    @torch.no_grad()
+    def generate_layout(self, room_mask, num_points, point_dim, batch_size=1, text=None, ret_traj=False, ddim=False,
+                        clip_denoised=False, batch_seeds=None, device="cpu", keep_empty=False):
+        samples = self.sample(room_mask, num_points, point_dim, batch_size, text=text, ret_traj=ret_traj, ddim=ddim,
+                              clip_denoised=clip_denoised, batch_seeds=batch_seeds)
+        return self.delete_empty_from_network_samples(samples, device=device, keep_empty=keep_empty)
+
+    @torch.no_grad()
+    def generate_layout_progressive(self, room_mask, num_points, point_dim, batch_size=1, text=None, ret_traj=False,
+                                    ddim=False, clip_denoised=False, batch_seeds=None, device="cpu", keep_empty=False,
+                                    num_step=100):
+        traj = self.sample(room_mask, num_points, point_dim, batch_size, text=text, ret_traj=ret_traj, ddim=ddim,
+                           clip_denoised=clip_denoised, batch_seeds=batch_seeds, freq=num_step)[1:]
+        return {num_step * i: self.delete_empty_from_network_samples(s, device=device, keep_empty=keep_empty)
+                for i, s in enumerate(traj)}
+
+    @torch.no_grad()
+    def complete_scene(self, room_mask, num_points, point_dim, partial_boxes, batch_size=1, ret_traj=False, ddim=False,
+                       clip_denoised=False, batch_seeds=None, device="cpu", keep_empty=False):
+        samples = self.sample(room_mask, num_points, point_dim, batch_size, partial_boxes=partial_boxes,
+                              ret_traj=ret_traj, ddim=ddim, clip_denoised=clip_denoised, batch_seeds=batch_seeds)
+        return self.delete_empty_from_network_samples(samples, device=device, keep_empty=keep_empty)
+
+    @torch.no_grad()
+    def arrange_scene(self, room_mask, num_points, point_dim, input_boxes, batch_size=1, ret_traj=False, ddim=False,
+                      clip_denoised=False, batch_seeds=None, device="cpu", keep_empty=False):
+        samples = self.sample(room_mask, num_points, point_dim, batch_size, input_boxes=input_boxes, ret_traj=ret_traj,
+                              ddim=ddim, clip_denoised=clip_denoised, batch_seeds=batch_seeds)
+        return self.delete_empty_from_network_samples(samples, device=device, keep_empty=keep_empty)
+
+    # ------------------------------------------------------------------------------------ post-filter
+    def _keep_rows(self, empty_logit_row0, keep_empty):
+        """Rows kept by the reference loop (:377-380, :424-427): drop slot i when the 'empty' logit of BATCH ROW 0
+        is >= 0 (network samples) -- the decision is shared by the whole batch, as in the reference."""
+        n = empty_logit_row0.shape[0]
+        if keep_empty:
+            return torch.arange(n)
+        return torch.nonzero(~empty_logit_row0, as_tuple=False).flatten()
+
+    @torch.no_grad()
+    def delete_empty_from_network_samples(self, samples, device="cpu", keep_empty=False):
+        samples = samples.detach().to("cpu")               # one device->host copy for the whole post-filter
+        tr, sz, bb, nc = self.translation_dim, self.size_dim, self.bbox_dim, self.class_dim
+        is_empty0 = samples[0, :, bb + nc - 1] >= 0
+        keep = self._keep_rows(is_empty0, keep_empty)
+        out = {
+            "class_labels": samples[:, keep, bb:bb + nc - 1].contiguous(),      # raw class scores, as the reference
+            "translations": samples[:, keep, 0:tr].contiguous(),
+            "sizes": samples[:, keep, tr:tr + sz].contiguous(),
+            "angles": samples[:, keep, tr + sz:bb].contiguous(),
+        }
+        if self.objfeat_dim > 0:
+            out["objfeats"] = samples[:, keep, bb + nc:bb + nc + self.objfeat_dim].contiguous()
+        return out
+
+    @torch.no_grad()
+    def delete_empty_boxes(self, samples_dict, device="cpu", keep_empty=False):
+        cl = samples_dict["class_labels"].detach().to("cpu")
+        keep = self._keep_rows(cl[0, :, -1] > 0, keep_empty)
+        out = {"class_labels": cl[:, keep, :self.class_dim - 1].contiguous()}
+        for k in ("translations", "sizes", "angles") + (("objfeats",) if self.objfeat_dim > 0 else ()):
+            out[k] = samples_dict[k].detach().to("cpu")[:, keep, :].contiguous()
+        return out
+
+
+def train_on_batch(model, optimizer, sample_params, config):
+    """reference :456-473: zero_grad, loss, backward, clip_grad_norm_(max_grad_norm), optimizer step.  All logged
+    scalars are fetched with one device->host copy; under torch.distributed the gradients are averaged over the
+    ranks (RCCL all-reduce over xGMI) before clipping, so every rank clips and steps identically."""
+    from ..ddp import average_gradients, clip_grad_norm_fused
+    optimizer.zero_grad()
+    loss, loss_dict = model.get_loss(sample_params)
+    loss.backward()
+    average_gradients(model)
+    grad_norm = clip_grad_norm_fused(model.parameters(), config["training"]["max_grad_norm"])
+    keys = list(loss_dict.keys())
+    packed = torch.stack([loss.detach(), grad_norm.detach()] + [loss_dict[k].detach() for k in keys]).tolist()
+    logger = StatsLogger.instance()
+    for k, v in zip(keys, packed[2:]):
+        logger[k].value = v
+    logger["gradnorm"].value = packed[1]
+    logger["lr"].value = optimizer.param_groups[0]['lr']
+    optimizer.step()
+    return packed[0]
+
+
+@torch.no_grad()
+def validate_on_batch(model, sample_params, config):
+    loss, loss_dict = model.get_loss(sample_params)
+    keys = list(loss_dict.keys())
+    packed = torch.stack([loss.detach()] + [loss_dict[k].detach() for k in keys]).tolist()
+    for k, v in zip(keys, packed[1:]):
+        StatsLogger.instance()[k].value = v
+    return packed[0]

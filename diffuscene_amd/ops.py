@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI (include/diffuscene_hip.h).
+
+PyTorch is used for device memory and streams only: every function takes CUDA(HIP) fp32 tensors,
+passes raw device pointers + the current torch stream to libdiffuscene_hip.so and returns the output
+tensor.  There is no CPU path: a CPU tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, MEAN_EPS, MEAN_V, MEAN_X0, SS_NONE, SS_PER_SCENE,  # noqa: F401
+                   SS_PER_SLOT, SS_PER_TOKEN, GemmArgs, WsItem)
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name="tensor", dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("diffuscene_amd: %s must live on a HIP device (no CPU fallback exists)" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("diffuscene_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _mat(t, name):
+    """2-D row-major view with contiguous columns; returns (ptr, ld)."""
+    _dev(t, name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError("diffuscene_amd: %s must be a 2-D tensor with contiguous rows, got shape %s strides %s"
+                           % (name, tuple(t.shape), t.stride()))
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+def as2d(w):
+    """(out, in, 1) conv weight or (out, in) linear weight -> (out, in) view."""
+    return w.view(w.shape[0], w.shape[1]) if w.dim() == 3 else w
+
+
+def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
+                   gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE):
+    """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
+    pointers only; the caller keeps the tensors alive."""
+    g = GemmArgs()
+    g.a1, g.lda1 = _mat(a, "a")
+    g.k1 = a.shape[1]
+    if a2 is not None:
+        g.a2, g.lda2 = _mat(a2, "a2")
+        g.k2 = a2.shape[1]
+        if a2.shape[0] != a.shape[0]:
+            raise RuntimeError("a and a2 row mismatch")
+    w2 = as2d(w)
+    g.w, g.ldw = _mat(w2, "w")
+    if w2.shape[1] != g.k1 + g.k2:
+        raise RuntimeError("weight K (%d) != activation K (%d)" % (w2.shape[1], g.k1 + g.k2))
+    g.m, g.n = a.shape[0], w2.shape[0]
+    g.y, g.ldy = _mat(y, "y")
+    if tuple(y.shape) != (g.m, g.n):
+        raise RuntimeError("output shape %s != (%d, %d)" % (tuple(y.shape), g.m, g.n))
+    if bias is not None:
+        g.bias = _dev(bias, "bias").data_ptr()
+    if residual is not None:
+        g.residual, g.ldr = _mat(residual, "residual")
+    g.act_in, g.act_out, g.batch = act_in, act_out, 1
+    if gamma is not None:
+        g.gamma, g.beta, g.eps = _dev(gamma).data_ptr(), _dev(beta).data_ptr(), eps
+        g.tokens_per_scene = tokens_per_scene
+    if scale_shift is not None:
+        g.scale_shift, g.ld_ss = _mat(scale_shift, "scale_shift")
+        g.ss_mode = ss_mode
+    return g
+
+
+def run_gemm(g, gn=False, stream=None):
+    name = "dsc_gemm_gn_silu_f32" if gn else "dsc_gemm_f32"
+    _lib.check(_lib.fn(name)(C.byref(g), stream if stream is not None else stream_ptr()), name)
+
+
+def gemm(a, w, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+    w2 = as2d(w)
+    if out is None:
+        out = torch.empty((a.shape[0], w2.shape[0]), device=a.device, dtype=torch.float32)
+    run_gemm(make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out))
+    return out
+
+
+def gemm_gn_silu(a, w_std, bias, gamma, beta, tokens_per_scene, a2=None, scale_shift=None, ss_mode=SS_NONE,
+                 residual=None, eps=1e-5, out=None):
+    w2 = as2d(w_std)
+    if out is None:
+        out = torch.empty((a.shape[0], w2.shape[0]), device=a.device, dtype=torch.float32)
+    run_gemm(make_gemm_args(a, w_std, out, bias, a2, residual, gamma=gamma, beta=beta, eps=eps,
+                            tokens_per_scene=tokens_per_scene, scale_shift=scale_shift, ss_mode=ss_mode), gn=True)
+    return out
+
+
+def linear_smallk(x, w, bias, act_out=ACT_NONE, out=None):
+    """x may be a column slice of a wider row-major tensor (arbitrary alignment)."""
+    xp, ldx = _mat(x, "x")
+    w2 = as2d(w)
+    wp, ldw = _mat(w2, "w")
+    if out is None:
+        out = torch.empty((x.shape[0], w2.shape[0]), device=x.device, dtype=torch.float32)
+    yp, ldy = _mat(out, "y")
+    _lib.check(_lib.fn("dsc_linear_smallk_f32")(xp, ldx, x.shape[1], wp, ldw,
+                                                bias.data_ptr() if bias is not None else None,
+                                                yp, ldy, x.shape[0], w2.shape[0], act_out, stream_ptr()),
+               "dsc_linear_smallk_f32")
+    return out
+
+
+def make_ws_items(pairs):
+    """pairs: list of (w2d, out2d) contiguous tensors -> ctypes array."""
+    arr = (WsItem * len(pairs))()
+    for i, (w, o) in enumerate(pairs):
+        w2, o2 = as2d(_dev(w)), as2d(_dev(o))
+        if not (w2.is_contiguous() and o2.is_contiguous()):
+            raise RuntimeError("weight_standardize needs contiguous matrices")
+        arr[i].w, arr[i].out, arr[i].rows, arr[i].cols = w2.data_ptr(), o2.data_ptr(), w2.shape[0], w2.shape[1]
+    return arr
+
+
+def weight_standardize(weights, outs=None, eps=1e-5):
+    """Batched (w - mean_row) * rsqrt(var_row + eps); returns the standardised copies."""
+    if outs is None:
+        outs = [torch.empty_like(as2d(w)) for w in weights]
+    for i in range(0, len(weights), _lib.WS_MAX):
+        chunk = list(zip(weights[i:i + _lib.WS_MAX], outs[i:i + _lib.WS_MAX]))
+        arr = make_ws_items(chunk)
+        _lib.check(_lib.fn("dsc_weight_standardize_f32")(arr, len(chunk), eps, stream_ptr()),
+                   "dsc_weight_standardize_f32")
+    return outs
+
+
+def layernorm(x, g, residual=None, eps=1e-5, out=None):
+    xp, ldx = _mat(x, "x")
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+    yp, ldy = _mat(out, "y")
+    rp, ldr = _mat(residual, "residual") if residual is not None else (None, 0)
+    _lib.check(_lib.fn("dsc_layernorm_f32")(xp, ldx, _dev(g).data_ptr(), rp, ldr, yp, ldy, x.shape[0], x.shape[1],
+                                            eps, stream_ptr()), "dsc_layernorm_f32")
+    return out
+
+
+def linear_attention(q, k, v, scenes, nq, nk, scale, out=None):
+    qp, ldq = _mat(q, "q")
+    kp, ldk = _mat(k, "k")
+    vp, ldv = _mat(v, "v")
+    if out is None:
+        out = torch.empty((q.shape[0], 128), device=q.device, dtype=torch.float32)
+    op, ldo = _mat(out, "out")
+    _lib.check(_lib.fn("dsc_linear_attention_f32")(qp, ldq, kp, ldk, vp, ldv, op, ldo, scenes, nq, nk, scale,
+                                                   stream_ptr()), "dsc_linear_attention_f32")
+    return out
+
+
+def attention(q, k, v, scenes, n, scale, out=None):
+    qp, ldq = _mat(q, "q")
+    kp, ldk = _mat(k, "k")
+    vp, ldv = _mat(v, "v")
+    if out is None:
+        out = torch.empty((q.shape[0], 128), device=q.device, dtype=torch.float32)
+    op, ldo = _mat(out, "out")
+    _lib.check(_lib.fn("dsc_attention_f32")(qp, ldq, kp, ldk, vp, ldv, op, ldo, scenes, n, scale, stream_ptr()),
+               "dsc_attention_f32")
+    return out
+
+
+def time_embedding(t, dim, table, freq, out=None):
+    _dev(t, "t", torch.int64)
+    if out is None:
+        out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    _lib.check(_lib.fn("dsc_time_embedding_f32")(t.data_ptr(), t.shape[0], dim,
+                                                 table.data_ptr() if table is not None else None,
+                                                 table.shape[0] if table is not None else 0,
+                                                 _dev(freq).data_ptr(), out.data_ptr(), stream_ptr()),
+               "dsc_time_embedding_f32")
+    return out
+
+
+def activation(x, act, out=None):
+    _dev(x)
+    if not x.is_contiguous():
+        raise RuntimeError("activation needs a contiguous tensor")
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.fn("dsc_activation_f32")(x.data_ptr(), out.data_ptr(), x.numel(), act, stream_ptr()),
+               "dsc_activation_f32")
+    return out
+
+
+# ---------------------------------------------------------------------------------- diffusion steps
+
+def _c(t, name):
+    _dev(t, name)
+    if not t.is_contiguous():
+        raise RuntimeError("diffuscene_amd: %s must be contiguous" % name)
+    return t
+
+
+def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac, want_v=False):
+    _c(x0, "x0"); _c(noise, "noise"); _dev(t, "t", torch.int64)
+    xt = torch.empty_like(x0)
+    v = torch.empty_like(x0) if want_v else None
+    b = x0.shape[0]
+    _lib.check(_lib.fn("dsc_q_sample_f32")(x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(),
+                                           sqrt_1mac.data_ptr(), xt.data_ptr(), v.data_ptr() if want_v else None,
+                                           b, x0.numel() // b, stream_ptr()), "dsc_q_sample_f32")
+    return (xt, v) if want_v else xt
+
+
+def p_sample(x_t, model_out, noise, t, ca, cb, coef1, coef2, sigma, mean_type, clip, out=None, x0_out=None):
+    _c(x_t, "x_t"); _c(model_out, "model_out"); _c(noise, "noise"); _dev(t, "t", torch.int64)
+    if out is None:
+        out = torch.empty_like(x_t)
+    b = x_t.shape[0]
+    _lib.check(_lib.fn("dsc_p_sample_f32")(x_t.data_ptr(), model_out.data_ptr(), noise.data_ptr(), t.data_ptr(),
+                                           ca.data_ptr() if ca is not None else None,
+                                           cb.data_ptr() if cb is not None else None,
+                                           coef1.data_ptr(), coef2.data_ptr(), sigma.data_ptr(), out.data_ptr(),
+                                           x0_out.data_ptr() if x0_out is not None else None,
+                                           mean_type, 1 if clip else 0, b, x_t.numel() // b, stream_ptr()),
+               "dsc_p_sample_f32")
+    return out
+
+
+def add_scalar_i64(t, delta):
+    _dev(t, "t", torch.int64)
+    _lib.check(_lib.fn("dsc_add_scalar_i64")(t.data_ptr(), t.numel(), delta, stream_ptr()), "dsc_add_scalar_i64")
+    return t
+
+
+def complete_overwrite(x, partial, noise, t, sqrt_ac, sqrt_1mac):
+    _c(x, "x"); _c(partial, "partial"); _c(noise, "noise"); _dev(t, "t", torch.int64)
+    b, n, c = x.shape
+    p = partial.shape[1]
+    _lib.check(_lib.fn("dsc_complete_overwrite_f32")(x.data_ptr(), partial.data_ptr(), noise.data_ptr(), t.data_ptr(),
+                                                     sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(), b, n, p, c,
+                                                     stream_ptr()), "dsc_complete_overwrite_f32")
+    return x

@@ -1,0 +1,115 @@
+"""hipGraph-captured reverse diffusion loop (reference p_sample_loop, diffusion_ddpm.py:355-371).
+
+The reference launches ~800 kernels per step from Python, 8e5 launches per sample.  Here ONE
+reverse step -- the denoiser launch plan (~140 kernels), the noise draw and the fused posterior step -- is
+captured once into a hipGraph whose only state is device-resident (x_t, the int64 timestep vector, the
+conditioning buffers of the plan) and replayed T times; the timestep is decremented by a kernel inside the graph.
+RNG draw order is the reference's: x_T first, then one draw per step (also at t == 0).
+"""
+import torch
+
+from . import ops
+from .networks.denoise_net import Unet1D
+
+_MEAN = {"eps": ops.MEAN_EPS, "x0": ops.MEAN_X0, "v": ops.MEAN_V}
+
+
+class NoiseReplay:
+    """noise_fn (protocol of diffusion_ddpm.py:345,355-356) that replays a pre-generated device tensor
+    ``buffer[i]`` for the i-th draw.  Usable eagerly and inside the captured graph (parity tests inject the
+    reference's noise this way)."""
+
+    def __init__(self, buffer):
+        self.buffer = buffer
+        self.i = 0
+
+    def __call__(self, size=None, dtype=None, device=None):
+        n = self.buffer[self.i]
+        self.i += 1
+        assert tuple(n.shape) == tuple(size), (tuple(n.shape), tuple(size))
+        return n
+
+
+class _StepGraph:
+    def __init__(self, diff, model, shape, device, condition, condition_cross, clip_denoised, replay=False):
+        B, N, C = shape
+        self.shape = shape
+        eng = model.engine(device)
+        self.plan = eng.prepare(B, N, condition, condition_cross)
+        tb = diff.tables(device)
+        ca, cb = diff._coeffs(tb)
+        self.x = torch.empty(shape, device=device, dtype=torch.float32)
+        self.t = torch.zeros((B,), device=device, dtype=torch.int64)
+        mean_type = _MEAN[diff.model_mean_type]
+        sigma = diff._sigma(tb)
+        plan = self.plan
+        self.replay = replay
+        self.noise_buf = None                                   # (T+1, B, N, C) when replaying
+        self.draw = torch.zeros((1,), device=device, dtype=torch.int64)
+
+        def step():
+            plan.x_in.copy_(self.x.view(B * N, C))
+            plan.t_in.copy_(self.t)
+            plan.run()
+            if self.replay:
+                noise = self.noise_buf.index_select(0, self.draw)[0]
+                ops.add_scalar_i64(self.draw, 1)
+            else:
+                noise = torch.randn(shape, dtype=torch.float, device=device)
+            ops.p_sample(self.x, plan.out.view(B, N, C), noise, self.t, ca, cb, tb["posterior_mean_coef1"],
+                         tb["posterior_mean_coef2"], sigma, mean_type, clip_denoised, out=self.x)
+            ops.add_scalar_i64(self.t, -1)
+
+        # warm-up on a side stream (loads every code object, sizes the allocator), then capture
+        self.x.normal_()
+        self.t.fill_(1)
+        if replay:
+            self.noise_buf = torch.zeros((diff.num_timesteps + 1,) + tuple(shape), device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            step()
+
+    def run(self, x_T, total_steps, noise_buffer=None):
+        self.x.copy_(x_T)
+        self.t.fill_(total_steps - 1)
+        if self.replay:
+            self.noise_buf[:noise_buffer.shape[0]].copy_(noise_buffer)
+            self.draw.fill_(1)                                  # draw 0 was x_T
+        for _ in range(total_steps):
+            self.graph.replay()
+        return self.x.clone()
+
+
+def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cross, clip_denoised, total_steps,
+                      noise_fn=torch.randn):
+    model = getattr(getattr(denoise_fn, "__self__", None), "model", None)
+    if not isinstance(model, Unet1D):
+        raise RuntimeError("graph sampling needs DiffusionPoint._denoise over a diffuscene_amd Unet1D")
+    device = torch.device(device)
+    with torch.no_grad():
+        replay = isinstance(noise_fn, NoiseReplay)
+        key = (id(model), tuple(shape), str(device), bool(clip_denoised), diff.model_mean_type, replay,
+               None if condition is None else (tuple(condition.shape), condition.stride(0) == 0),
+               None if condition_cross is None else tuple(condition_cross.shape))
+        g = diff._graphs.get(key)
+        eng = model.engine(device)
+        if g is None or g.plan is not eng.plans.get(_plan_key(g)):
+            g = _StepGraph(diff, model, tuple(shape), device, condition, condition_cross, clip_denoised, replay)
+            diff._graphs = {key: g}           # one live graph per diffusion object
+        else:
+            eng.prepare(shape[0], shape[1], condition, condition_cross)   # refresh weights + conditioning buffers
+        if replay:
+            return g.run(noise_fn.buffer[0], total_steps, noise_fn.buffer)
+        x_T = torch.randn(shape, dtype=torch.float, device=device)
+        return g.run(x_T, total_steps)
+
+
+def _plan_key(g):
+    p = g.plan
+    return (p.B, p.N, p.ctx_mode, 0 if p.ctx_in is None else p.ctx_in.shape[1], p.L,
+            0 if p.cross_in is None else p.cross_in.shape[1])

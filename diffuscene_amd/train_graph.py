@@ -1,0 +1,90 @@
+"""Training-side graph of the DDPM step: autograd over the HIP kernels and the loss of reference p_losses.
+
+``unet1d_forward_autograd`` runs the same kernels as the inference plan but records what the hand-written
+backward kernels (csrc/train.hip) need; ``diffusion_losses`` is the loss of diffusion_ddpm.py:556-652.
+"""
+import torch
+
+from .networks.loss import axis_aligned_bbox_overlaps_3d
+
+
+def unet1d_forward_autograd(net, x, t, context, context_cross):
+    from .autograd_ops import unet1d_train_forward
+    return unet1d_train_forward(net, x, t, context, context_cross)
+
+
+def _mse(target, out, a, b):
+    return ((target[:, :, a:b] - out[:, :, a:b]) ** 2).mean(dim=(1, 2))
+
+
+def diffusion_losses(diff, tb, data_start, data_t, target, denoise_out, t):
+    """Separated MSE terms, loss_weight[t] scaling and the 3-D IoU regulariser of reference p_losses
+    (diffusion_ddpm.py:558-652).  Small (B,N,C)/(B,N,N) tensors: device torch ops under autograd."""
+    B = data_start.shape[0]
+    tr, sz, bb = diff.translation_dim, diff.size_dim, diff.bbox_dim
+    nc, no, nf = diff.class_dim, diff.objectness_dim, diff.objfeat_dim
+    lw_t = tb["loss_weight"][t]
+    if diff.room_arrange_condition:
+        assert data_start.shape[-1] == tr + diff.angle_dim
+        loss_trans = _mse(target, denoise_out, 0, tr)
+        loss_angle = _mse(target, denoise_out, tr, data_start.shape[-1])
+        if diff.loss_separate:
+            losses = loss_trans + loss_angle
+        else:
+            losses = ((target - denoise_out) ** 2).mean(dim=(1, 2))
+        return losses * lw_t, {'loss.trans': loss_trans.mean(), 'loss.angle': loss_angle.mean()}
+    if data_start.shape[-1] != no + nc + bb + nf:
+        print('unimplement point dim is: ', data_start.shape[-1])
+        raise NotImplementedError
+    loss_trans = _mse(target, denoise_out, 0, tr)
+    loss_size = _mse(target, denoise_out, tr, tr + sz)
+    loss_angle = _mse(target, denoise_out, tr + sz, bb)
+    loss_bbox = _mse(target, denoise_out, 0, bb)
+    loss_class = _mse(target, denoise_out, bb, bb + nc)
+    loss_object = _mse(target, denoise_out, bb + nc - 1, bb + nc) if no == 0 else \
+        _mse(target, denoise_out, bb + nc, bb + nc + no)
+    loss_objfeat = torch.zeros(B, device=data_start.device) if nf == 0 else \
+        _mse(target, denoise_out, bb + nc + no, data_start.shape[-1])
+    if diff.loss_separate:
+        losses = loss_bbox + loss_class
+        if no > 0:
+            losses = losses + loss_object
+        if nf > 0:
+            losses = losses + loss_objfeat
+    else:
+        losses = ((target - denoise_out) ** 2).mean(dim=(1, 2))
+    losses_weight = losses * lw_t
+    if diff.loss_iou:
+        if diff.model_mean_type == 'eps':
+            x_recon = diff._predict_xstart_from_eps(data_t, t, eps=denoise_out)
+        elif diff.model_mean_type == 'x0':
+            x_recon = denoise_out
+        else:
+            x_recon = diff._predict_start_from_v(data_t, t, v=denoise_out)
+        x_recon = torch.clamp(x_recon, -1.0, 1.0)
+        if no > 0:
+            valid = (x_recon[:, :, bb + nc:bb + nc + no] >= 0).float().squeeze(2)
+        else:
+            valid = (x_recon[:, :, bb + nc - 1:bb + nc] <= 0).float().squeeze(2)
+        dev = data_start.device
+        ctr = diff.descale_to_origin(x_recon[:, :, 0:tr], diff._centroids_min.to(dev), diff._centroids_max.to(dev))
+        siz = diff.descale_to_origin(x_recon[:, :, tr:tr + sz], diff._sizes_min.to(dev), diff._sizes_max.to(dev))
+        corners = torch.cat([ctr - siz, ctr + siz], dim=-1)
+        assert corners.shape[-1] == 6
+        bbox_iou = axis_aligned_bbox_overlaps_3d(corners, corners)
+        mask = valid[:, :, None] * valid[:, None, :]
+        iou_valid = bbox_iou * mask
+        denom = mask.sum(dim=(1, 2)) + 1e-6
+        bbox_iou_valid_avg = iou_valid.sum(dim=(1, 2)) / denom
+        w_iou = tb["alphas_cumprod"][t].reshape(B, 1, 1)
+        loss_iou_valid_avg = (w_iou * 0.1 * iou_valid).sum(dim=(1, 2)) / denom
+        losses_weight = losses_weight + loss_iou_valid_avg
+    else:
+        loss_iou_valid_avg = torch.zeros(B, device=data_start.device)
+        bbox_iou_valid_avg = torch.zeros(B, device=data_start.device)
+    return losses_weight, {
+        'loss.bbox': loss_bbox.mean(), 'loss.trans': loss_trans.mean(), 'loss.size': loss_size.mean(),
+        'loss.angle': loss_angle.mean(), 'loss.class': loss_class.mean(), 'loss.object': loss_object.mean(),
+        'loss.objfeat': loss_objfeat.mean(), 'loss.liou': loss_iou_valid_avg.mean(),
+        'loss.bbox_iou': bbox_iou_valid_avg.mean(),
+    }

@@ -1,0 +1,161 @@
+/*
+ * diffuscene_hip.h -- C ABI of libdiffuscene_hip.so (gfx950 / MI355X).
+ *
+ * The reference (tangjiapeng/DiffuScene) has no FFI on this path: its DDPM hot path is pure
+ * PyTorch (scene_synthesis/networks/denoise_net.py, diffusion_ddpm.py, loss.py).  The drop-in
+ * boundary is therefore the Python class surface; this header is the
+ * thin C layer underneath it.  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless stated; the caller (PyTorch) owns all
+ *    memory, the library allocates nothing and keeps no global state;
+ *  - activations are token-major: row = b * N + n (scene b, object slot n), channels contiguous.
+ *    The reference's (B, C, N) conv layout is never materialised;
+ *  - every call enqueues on `stream` and returns immediately (capturable in a hipGraph);
+ *  - return value: 0 on success, a negative DSC_E* code for rejected arguments, or a positive
+ *    hipError_t from the launch.  Nothing is silently clamped.
+ */
+#ifndef DIFFUSCENE_HIP_H
+#define DIFFUSCENE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dsc_stream_t; /* hipStream_t */
+
+#define DSC_EINVAL   (-1)  /* bad shape / null pointer */
+#define DSC_EALIGN   (-2)  /* pointer or leading dimension not 16-byte aligned where required */
+#define DSC_ERANGE   (-3)  /* size outside what the kernel supports (e.g. tokens_per_scene > 160) */
+
+#define DSC_ACT_NONE 0
+#define DSC_ACT_GELU 1   /* exact erf GELU (nn.GELU default) */
+#define DSC_ACT_SILU 2
+
+#define DSC_SS_NONE      0
+#define DSC_SS_PER_TOKEN 1   /* scale_shift row = token           (context-conditioned ResnetBlock) */
+#define DSC_SS_PER_SCENE 2   /* scale_shift row = token / N       (time-conditioned ResnetBlock)    */
+#define DSC_SS_PER_SLOT  3   /* scale_shift row = token % N       (instance embedding shared over B)*/
+
+#define DSC_HEADS    4
+#define DSC_DIM_HEAD 32
+
+int dsc_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM with fused epilogues:  Y = epilogue( act_in([A1 | A2]) . W^T + bias )
+ *
+ * Replaces every 1x1 nn.Conv1d / nn.Linear on the path (denoise_net.py:163,183,188,214,217,244,
+ * 245,397,419-421,440,459,487-503) including the torch.cat of skip connections (:562,:566,:573),
+ * which becomes the second K segment.  Arithmetic: v_mfma_f32_32x32x2_f32, exact fp32.
+ *   k1, k2 multiples of 32; a1/a2/w rows 16-byte aligned.  y/residual may have any alignment.
+ *   batch > 1 launches a grouped GEMM: group z uses pointers advanced by the s* element strides.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dsc_gemm_args {
+    const float* a1; int64_t lda1; int32_t k1;
+    const float* a2; int64_t lda2; int32_t k2;   /* k2 = 0 -> single segment */
+    const float* w;  int64_t ldw;                /* [n][k1+k2] */
+    const float* bias;                           /* [n] or NULL */
+    const float* residual; int64_t ldr;          /* added after act_out, or NULL */
+    float* y; int64_t ldy;
+    int32_t m, n;
+    int32_t act_in;                              /* applied to A while staging (SiLU of ResnetBlock.mlp, :181-184) */
+    int32_t act_out;
+    int32_t batch; int64_t sa1, sa2, sw, sbias, sres, sy;
+    /* ---- GroupNorm epilogue (dsc_gemm_gn_silu_f32 only) ---- */
+    const float* gamma; const float* beta; float eps;
+    int32_t tokens_per_scene;                    /* N: GroupNorm reduces over 64 channels x N tokens (:164) */
+    const float* scale_shift; int64_t ld_ss; int32_t ss_mode; /* row layout [scale(n) | shift(n)] */
+} dsc_gemm_args;
+
+int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
+
+/* Block.forward (denoise_net.py:167-176) as ONE kernel:
+ *   Y = SiLU( GroupNorm8( [A1|A2].W^T + bias ) * (scale + 1) + shift ) (+ residual)
+ * W must already be weight-standardised (dsc_weight_standardize_f32).  n must be a multiple of 128,
+ * groups are 64 channels wide (nn.GroupNorm(8, 512)), m a multiple of tokens_per_scene <= 160. */
+int dsc_gemm_gn_silu_f32(const dsc_gemm_args* args, dsc_stream_t stream);
+
+/* Small-K linear for un-aligned inputs (first layer of _encoder_mlp on slices of the (B,N,C)
+ * tensor, denoise_net.py:487,513-524; init_conv of the 5-channel re-arrangement model, :397):
+ *   y[m][n] = act( sum_k x[m*ldx + k] * w[n*ldw + k] + bias[n] ),  k_in <= 64. */
+int dsc_linear_smallk_f32(const float* x, int64_t ldx, int32_t k_in, const float* w, int64_t ldw,
+                          const float* bias, float* y, int64_t ldy, int32_t m, int32_t n,
+                          int32_t act_out, dsc_stream_t stream);
+
+/* WeightStandardizedConv2d.forward weight path (denoise_net.py:84-89):
+ *   out[o][:] = (w[o][:] - mean_o) * rsqrt(var_o + eps), biased variance over the row.
+ * Batched: up to DSC_WS_MAX matrices per launch. */
+#define DSC_WS_MAX 64
+typedef struct dsc_ws_item { const float* w; float* out; int32_t rows; int32_t cols; } dsc_ws_item;
+int dsc_weight_standardize_f32(const dsc_ws_item* items, int32_t count, float eps, dsc_stream_t stream);
+
+/* LayerNorm over channels with gain (denoise_net.py:98-102), optionally + residual (Residual, :39-45):
+ *   y[r][:] = (x[r][:] - mean_r) * rsqrt(var_r + eps) * g[:] (+ residual[r][:]);  d must be 512. */
+int dsc_layernorm_f32(const float* x, int64_t ldx, const float* g, const float* residual, int64_t ldr,
+                      float* y, int64_t ldy, int32_t m, int32_t d, float eps, dsc_stream_t stream);
+
+/* LinearAttention / LinearAttentionCross core (denoise_net.py:226-234, :288-296), 4 heads x 32:
+ *   q <- softmax over the 32 head channels, * scale; k <- softmax over the nk tokens of the scene;
+ *   ctx[d][e] = sum_j k[j][d] v[j][e];  out[i][e] = sum_d ctx[d][e] q[i][d].
+ * q rows b*nq+i (ldq), k/v rows b*nk+j (ldk/ldv); head h uses columns [32h, 32h+32). nq, nk <= 160. */
+int dsc_linear_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                             const float* v, int64_t ldv, float* out, int64_t ldo,
+                             int32_t scenes, int32_t nq, int32_t nk, float scale, dsc_stream_t stream);
+
+/* Attention core (denoise_net.py:252-258): softmax_j( scale * q_i . k_j ) v_j per scene and head; n <= 160. */
+int dsc_attention_f32(const float* q, int64_t ldq, const float* k, int64_t ldk,
+                      const float* v, int64_t ldv, float* out, int64_t ldo,
+                      int32_t scenes, int32_t n, float scale, dsc_stream_t stream);
+
+/* SinusoidalPosEmb (denoise_net.py:132-139): out[b] = table[t[b]] when 0 <= t[b] < table_rows (the
+ * table is computed by the host with the reference's own fp32 expression), else computed in place
+ * from freq[dim/2] as [sin(t f) | cos(t f)]. */
+int dsc_time_embedding_f32(const int64_t* t, int32_t b, int32_t dim, const float* table, int32_t table_rows,
+                           const float* freq, float* out, dsc_stream_t stream);
+
+/* y = act(x) elementwise (SiLU on the conditioning before ResnetBlock.mlp's Linear, :181-184). */
+int dsc_activation_f32(const float* x, float* y, int64_t count, int32_t act, dsc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diffusion process (diffusion_ddpm.py).  Coefficient tables live on the device (the reference
+ * re-uploads them on every call, :220,:232,:284); t is int64 on the device; `inner` = N*C.
+ * These kernels are compiled with -ffp-contract=off and reproduce the reference's fp32
+ * expression order bit for bit.
+ * ------------------------------------------------------------------------------------------- */
+
+/* q_sample (:276-286) and, if v_out != NULL, _predict_v (:230-234) in one pass:
+ *   x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise ;  v = sqrt_ac[t] * noise - sqrt_1mac[t] * x0 */
+int dsc_q_sample_f32(const float* x0, const float* noise, const int64_t* t,
+                     const float* sqrt_ac, const float* sqrt_1mac,
+                     float* x_t, float* v_out, int32_t b, int64_t inner, dsc_stream_t stream);
+
+/* p_mean_variance + p_sample for model_var_type 'fixedsmall' (:242-264, :305-352):
+ *   x0 = (mean_type v)   ca[t]*x_t - cb[t]*model_out      ca=sqrt_ac,        cb=sqrt_1mac
+ *        (mean_type eps) ca[t]*x_t - cb[t]*model_out      ca=sqrt_recip_ac,  cb=sqrt_recipm1_ac
+ *        (mean_type x0)  model_out
+ *   clamp to [-1,1] if clip; mean = coef1[t]*x0 + coef2[t]*x_t; out = mean + (t != 0) * sigma[t] * noise
+ * sigma[t] = exp(0.5 * posterior_log_variance_clipped[t]) is tabulated by the host. */
+#define DSC_MEAN_EPS 0
+#define DSC_MEAN_X0  1
+#define DSC_MEAN_V   2
+int dsc_p_sample_f32(const float* x_t, const float* model_out, const float* noise, const int64_t* t,
+                     const float* ca, const float* cb, const float* coef1, const float* coef2,
+                     const float* sigma, float* out, float* x0_out /* may be NULL */,
+                     int32_t mean_type, int32_t clip, int32_t b, int64_t inner, dsc_stream_t stream);
+
+/* In-graph timestep bookkeeping for the captured reverse loop (:365-366): t[i] += delta. */
+int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t stream);
+
+/* Inpainting overwrite of p_sample_loop_complete (:462-466): rows [0,p) of every scene of x
+ * (b, n, c) are replaced by q_sample(partial, t, noise) (partial/noise are (b, p, c)). */
+int dsc_complete_overwrite_f32(float* x, const float* partial, const float* noise, const int64_t* t,
+                               const float* sqrt_ac, const float* sqrt_1mac,
+                               int32_t b, int32_t n, int32_t p, int32_t c, dsc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFUSCENE_HIP_H */

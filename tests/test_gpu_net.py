@@ -1,0 +1,213 @@
+"""GPU: the HIP denoiser / DDPM path against the committed golden vectors (real reference outputs) and against the
+oracle on other shapes.  Tolerance: 1e-4 relative on the predicted attribute tensor (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_torch as R  # noqa: E402
+from oracle import weights as W  # noqa: E402
+from oracle.make_golden import CASES, case_inputs, noise_list  # noqa: E402
+
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+_NETS = {}
+
+
+def build(name, **diff_kwargs):
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    kw = CASES[name][0]
+    if name not in _NETS:
+        net = Unet1D(**kw)
+        net.load_state_dict(W.synth_state_dict(kw))
+        _NETS[name] = net.to(dev())
+    cfg = dict(objectness_dim=kw.get("objectness_dim", 1), class_dim=kw.get("class_dim", 21),
+               angle_dim=kw.get("angle_dim", 1), objfeat_dim=kw.get("objfeat_dim", 0))
+    cfg.update(diff_kwargs.pop("config_extra", {}))
+    return _NETS[name], DiffusionPoint(_NETS[name], cfg, **diff_kwargs)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "unet_forward.npz"))
+    kw, x, t, cond, cross = case_inputs(name)
+    net, _ = build(name)
+    with torch.no_grad():
+        out = net(x.to(dev()), t.to(dev()), cond.to(dev()), cross.to(dev()) if cross is not None else None)
+    r = rel(out, g[name])
+    print(name, "forward rel err vs reference:", r)
+    assert out.shape == g[name].shape and out.is_contiguous()
+    assert r < TOL
+
+
+def test_shared_and_per_token_context_agree():
+    """stride-0 (per-slot) conditioning path == materialised (B,N,128) path."""
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    net, _ = build("uncond_bedroom")
+    B, N, _c = x.shape
+    shared = cond[0].to(dev())[None].expand(B, N, 128)
+    with torch.no_grad():
+        a = net(x.to(dev()), t.to(dev()), shared, None)
+        b = net(x.to(dev()), t.to(dev()), shared.contiguous(), None)
+    assert rel(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("B,N,name", [(3, 80, "uncond_living"), (5, 21, "uncond_living"), (2, 33, "uncond_bedroom")])
+def test_forward_matches_oracle_other_shapes(B, N, name):
+    kw = CASES[name][0]
+    net, _ = build(name)
+    x = W.synth_scene_batch(B, N, kw["class_dim"], 32, seed=3)
+    t = torch.tensor([(91 + 307 * i) % 1000 for i in range(B)], dtype=torch.int64)
+    cond = W.synth_condition(B, N, 128, seed=3, shared=False)
+    with torch.no_grad():
+        out = net(x.to(dev()), t.to(dev()), cond.to(dev()), None)
+        ref = R.unet1d_forward(W.synth_state_dict(kw), kw, x, t, cond, None)
+    r = rel(out, ref)
+    print("B=%d N=%d rel err vs oracle: %g" % (B, N, r))
+    assert r < TOL
+
+
+def _replay(seq):
+    from diffuscene_amd.sampler import NoiseReplay
+    return NoiseReplay(torch.stack(seq).to(dev()))
+
+
+class _ListReplay:
+    def __init__(self, seq):
+        self.seq, self.i = [s.to(dev()) for s in seq], 0
+
+    def __call__(self, size=None, dtype=None, device=None):
+        n = self.seq[self.i]
+        self.i += 1
+        assert tuple(n.shape) == tuple(size)
+        return n
+
+
+def test_reverse_chains_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    net, diff = build("uncond_bedroom", time_num=50, model_mean_type="v")
+    cd = cond.to(dev())
+    with torch.no_grad():
+        s = diff.gen_samples((B, N, C), dev(), condition=cd, noise_fn=_replay(noise_list([(B, N, C)] * 51, 1, "chain50_")),
+                             clip_denoised=True, graph=False)
+        print("T50 chain rel err:", rel(s, g["uncond_T50"]))
+        assert rel(s, g["uncond_T50"]) < TOL
+        s = diff.gen_samples((B, N, C), dev(), condition=cd, noise_fn=_replay(noise_list([(B, N, C)] * 51, 3, "noclip_")),
+                             clip_denoised=False, graph=False)
+        assert rel(s, g["uncond_noclip_T50"]) < TOL
+        shapes = [(B, N, C)]
+        for _ in range(50):
+            shapes += [(B, 3, C), (B, N, C)]
+        s = diff.complete_samples((B, N, C), dev(), condition=cd, noise_fn=_ListReplay(noise_list(shapes, 2, "complete_")),
+                                  clip_denoised=True, partial_boxes=x[:, :3, :].contiguous().to(dev()))
+        print("completion chain rel err:", rel(s, g["complete_T50"]))
+        assert rel(s, g["complete_T50"]) < TOL
+
+
+def test_graph_replay_equals_eager_and_golden(golden_dir):
+    """The captured hipGraph step replayed 50 times == the eager loop, bit for bit, and both match the reference."""
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    net, diff = build("uncond_bedroom", time_num=50, model_mean_type="v")
+    seq = noise_list([(B, N, C)] * 51, 1, "chain50_")
+    with torch.no_grad():
+        eager = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=_replay(seq), graph=False)
+        graph = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=_replay(seq), graph=True)
+        again = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=_replay(seq), graph=True)
+    assert torch.equal(eager, graph) and torch.equal(graph, again)
+    assert rel(graph, g["uncond_T50"]) < TOL
+    with torch.no_grad():
+        s = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), graph=True)       # device RNG inside the graph
+    assert torch.isfinite(s).all() and 0.05 < float(s.abs().mean()) < 2.0
+
+
+def test_text_and_arrange_chains(golden_dir):
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, cross = case_inputs("text_bedroom")
+    net, diff = build("text_bedroom", time_num=20, model_mean_type="v")
+    with torch.no_grad():
+        s = diff.gen_samples(tuple(x.shape), dev(), condition=cond.to(dev()), condition_cross=cross.to(dev()),
+                             noise_fn=_replay(noise_list([tuple(x.shape)] * 21, 4, "text_")), graph=False)
+    print("text chain rel err:", rel(s, g["text_T20"]))
+    assert rel(s, g["text_T20"]) < TOL
+    kw, x, t, cond, _ = case_inputs("rearrange_living")
+    B, N = x.shape[:2]
+    full = W.synth_scene_batch(B, N, 25, 32, 5)
+    net, diff = build("rearrange_living", time_num=50, model_mean_type="v", config_extra={"room_arrange_condition": True})
+    with torch.no_grad():
+        s = diff.arrange_samples((B, N, 65), dev(), condition=cond.to(dev()),
+                                 noise_fn=_ListReplay(noise_list([(B, N, 5)] * 51, 5, "arrange_")),
+                                 clip_denoised=True, input_boxes=full.to(dev()))
+    print("arrange chain rel err:", rel(s, g["arrange_T50"]))
+    assert rel(s, g["arrange_T50"]) < TOL
+
+
+def test_full_1000_step_chain_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    _, N, C = x.shape
+    net, diff = build("uncond_bedroom", time_num=1000, model_mean_type="v")
+    seq = noise_list([(1, N, C)] * 1001, 1, "chain1000_")
+    with torch.no_grad():
+        s = diff.gen_samples((1, N, C), dev(), condition=cond[:1].to(dev()), noise_fn=_replay(seq), graph=True)
+    r = rel(s, g["uncond_T1000"])
+    print("1000-step chain rel err vs reference:", r)
+    assert r < TOL
+
+
+def test_size_independent_properties_at_full_size():
+    """B=256, N=80 (BASELINE size): scenes are independent, so any slice of the batch must reproduce the full-batch
+    rows; and permuting batch rows permutes outputs."""
+    name = "uncond_living"
+    kw = CASES[name][0]
+    net, _ = build(name)
+    B, N = 256, 80
+    x = W.synth_scene_batch(B, N, 25, 32, seed=11).to(dev())
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(5)).to(dev())
+    cond = W.synth_condition(B, N, 128, seed=11).to(dev())
+    with torch.no_grad():
+        full = net(x, t, cond, None)
+        part = net(x[40:48].contiguous(), t[40:48].contiguous(), cond[40:48], None)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(6)).to(dev())
+        shuf = net(x[perm].contiguous(), t[perm].contiguous(), cond, None)
+    assert torch.isfinite(full).all()
+    assert rel(part, full[40:48]) < 1e-5
+    assert rel(shuf, full[perm]) < 1e-5
+    ref = R.unet1d_forward(W.synth_state_dict(kw), kw, x[:2].cpu(), t[:2].cpu(), cond[:2].cpu(), None)
+    assert rel(full[:2], ref) < TOL
+
+
+def test_scene_layout_wrapper_generates():
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 62, "latent_dim": 0,
+           "room_mask_condition": False, "sample_num_points": 12, "objectness_dim": 0, "objfeat_dim": 32,
+           "class_dim": 22, "angle_dim": 2, "learnable_embedding": True, "instance_condition": True,
+           "instance_emb_dim": 128,
+           "diffusion_kwargs": dict(schedule_type="linear", beta_start=1e-4, beta_end=0.02, time_num=20,
+                                    loss_type="mse", model_mean_type="v", model_var_type="fixedsmall",
+                                    loss_separate=True, loss_iou=False, train_stats_file=None),
+           "net_kwargs": dict(W.UNCOND_BEDROOM)}
+    m = DiffusionSceneLayout_DDPM(23, None, cfg).to(dev())
+    room = torch.zeros(1, 1, 64, 64, device=dev())
+    boxes = m.generate_layout(room, num_points=12, point_dim=62, batch_size=1, clip_denoised=True, device="cpu")
+    assert set(boxes) == {"class_labels", "translations", "sizes", "angles", "objfeats"}
+    n = boxes["translations"].shape[1]
+    assert boxes["class_labels"].shape == (1, n, 21) and boxes["objfeats"].shape == (1, n, 32)
+    assert all(v.device.type == "cpu" for v in boxes.values())

@@ -1,0 +1,237 @@
+"""GPU: every C-ABI kernel against a plain fp32/fp64 torch restatement of the same reference op (oracle pieces).
+Tolerances are written per test; elementwise diffusion steps must be BIT-EXACT."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_torch as R  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 128, 32), (37, 5, 64), (160, 384, 512), (333, 25, 512), (256, 1024, 2048),
+                                   (1000, 130, 96)])
+def test_gemm_plain(m, n, k):
+    from diffuscene_amd import ops
+    a, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2), rnd(n, seed=3)
+    y = ops.gemm(a.to(dev()), w.to(dev()), b.to(dev()))
+    ref = a.double() @ w.double().T + b.double()
+    assert rel(y, ref) < 2e-6, (m, n, k, rel(y, ref))
+
+
+def test_gemm_transpose_detecting_identity():
+    """A = I-like asymmetric check: catches a swapped C-write or operand transpose."""
+    from diffuscene_amd import ops
+    m, n, k = 96, 64, 64
+    a = torch.zeros(m, k)
+    for i in range(m):
+        a[i, (i * 7) % k] = 1.0 + i
+    w = torch.arange(n * k, dtype=torch.float32).reshape(n, k) / 100.0
+    y = ops.gemm(a.to(dev()), w.to(dev()))
+    assert rel(y, a.double() @ w.double().T) < 1e-6
+
+
+@pytest.mark.parametrize("act_in,act_out", [(0, 1), (2, 0), (0, 2)])
+def test_gemm_epilogues_two_segments_residual(act_in, act_out):
+    from diffuscene_amd import ops
+    m, n = 200, 512
+    a1, a2, w, b, r = rnd(m, 512, seed=4), rnd(m, 512, seed=5), rnd(n, 1024, seed=6, scale=0.05), rnd(n, seed=7), rnd(m, n, seed=8)
+    y = ops.gemm(a1.to(dev()), w.to(dev()), b.to(dev()), a2=a2.to(dev()), residual=r.to(dev()), act_in=act_in, act_out=act_out)
+    A = torch.cat([a1, a2], 1).double()
+    if act_in == 2:
+        A = F.silu(A)
+    z = A @ w.double().T + b.double()
+    z = F.gelu(z) if act_out == 1 else (F.silu(z) if act_out == 2 else z)
+    assert rel(y, z + r.double()) < 3e-6
+
+
+def test_gemm_strided_output_and_input_views():
+    """decoder heads write at a column offset of the (M, C) output (ldy = 65, unaligned); A may be a column view."""
+    from diffuscene_amd import ops
+    m = 77
+    abuf = rnd(m, 1024, seed=9).to(dev())
+    a = abuf[:, 512:]
+    w, b = rnd(25, 512, seed=10), rnd(25, seed=11)
+    out = torch.zeros(m, 65, device=dev())
+    ops.gemm(a, w.to(dev()), b.to(dev()), out=out[:, 8:33])
+    ref = abuf[:, 512:].double().cpu() @ w.double().T + b.double()
+    assert rel(out[:, 8:33], ref) < 2e-6
+    assert float(out[:, :8].abs().max()) == 0 and float(out[:, 33:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,N,mode", [(3, 80, 2), (7, 21, 1), (9, 12, 3), (1, 33, 0), (2, 160, 2), (5, 50, 3)])
+def test_gemm_groupnorm_silu_block(B, N, mode):
+    """Block.forward (denoise_net.py:167-176): WS-conv output -> GroupNorm(8) -> (scale+1, shift) -> SiLU, + residual."""
+    from diffuscene_amd import ops
+    M, D = B * N, 512
+    a, w, b = rnd(M, D, seed=12), rnd(D, D, seed=13, scale=0.1), rnd(D, seed=14)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=15), 0.1 * rnd(D, seed=16)
+    res = rnd(M, D, seed=17)
+    rows = {0: 0, 1: M, 2: B, 3: N}[mode]
+    ss = rnd(rows, 2 * D, seed=18) if rows else None
+    y = ops.gemm_gn_silu(a.to(dev()), w.to(dev()), b.to(dev()), gamma.to(dev()), beta.to(dev()), N,
+                         scale_shift=ss.to(dev()) if ss is not None else None, ss_mode=mode, residual=res.to(dev()))
+    z = (a.double() @ w.double().T + b.double()).reshape(B, N, D).permute(0, 2, 1)        # (B, C, N)
+    g = F.group_norm(z, 8, gamma.double(), beta.double(), eps=1e-5)
+    if mode:
+        if mode == 1:
+            e = ss.reshape(B, N, 2 * D)
+        elif mode == 2:
+            e = ss[:, None, :].expand(B, N, 2 * D)
+        else:
+            e = ss[None].expand(B, N, 2 * D)
+        e = e.double().permute(0, 2, 1)
+        g = g * (e[:, :D] + 1) + e[:, D:]
+    ref = F.silu(g).permute(0, 2, 1).reshape(M, D) + res.double()
+    assert rel(y, ref) < 5e-6, rel(y, ref)
+
+
+def test_gemm_gn_two_segments():
+    from diffuscene_amd import ops
+    B, N, D = 4, 21, 512
+    M = B * N
+    a1, a2, w, b = rnd(M, D, seed=19), rnd(M, D, seed=20), rnd(D, 2 * D, seed=21, scale=0.1), rnd(D, seed=22)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=23), 0.1 * rnd(D, seed=24)
+    y = ops.gemm_gn_silu(a1.to(dev()), w.to(dev()), b.to(dev()), gamma.to(dev()), beta.to(dev()), N, a2=a2.to(dev()))
+    z = (torch.cat([a1, a2], 1).double() @ w.double().T + b.double()).reshape(B, N, D).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(z, 8, gamma.double(), beta.double(), eps=1e-5)).permute(0, 2, 1).reshape(M, D)
+    assert rel(y, ref) < 5e-6
+
+
+def test_weight_standardize():
+    from diffuscene_amd import ops
+    ws = [rnd(512, 512, seed=30), rnd(512, 1024, seed=31) + 0.3, rnd(64, 40, seed=32)]
+    outs = ops.weight_standardize([w.to(dev()) for w in ws])
+    for w, o in zip(ws, outs):
+        w3 = w.double()[:, :, None]
+        mean = w3.mean(dim=(1, 2), keepdim=True)
+        var = w3.var(dim=(1, 2), unbiased=False, keepdim=True)
+        ref = ((w3 - mean) * (var + 1e-5).rsqrt())[:, :, 0]
+        assert rel(o, ref) < 2e-6
+
+
+def test_layernorm_with_residual():
+    from diffuscene_amd import ops
+    x, g, r = rnd(301, 512, seed=33) * 3 + 0.5, 1 + 0.1 * rnd(512, seed=34), rnd(301, 512, seed=35)
+    y = ops.layernorm(x.to(dev()), g.to(dev()), residual=r.to(dev()))
+    xd = x.double()
+    ref = (xd - xd.mean(1, keepdim=True)) * (xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * g.double() + r.double()
+    assert rel(y, ref) < 2e-6
+    y2 = ops.layernorm(x.to(dev()), g.to(dev()))
+    assert rel(y2, ref - r.double()) < 2e-6
+
+
+@pytest.mark.parametrize("B,N", [(3, 80), (5, 12), (2, 21), (1, 160)])
+def test_linear_attention(B, N):
+    from diffuscene_amd import ops
+    qkv = rnd(B * N, 384, seed=36) * 2
+    out = ops.linear_attention(qkv.to(dev())[:, :128], qkv.to(dev())[:, 128:256], qkv.to(dev())[:, 256:], B, N, N, 32 ** -0.5)
+    t = qkv.double().reshape(B, N, 3, 4, 32).permute(2, 0, 3, 4, 1)          # (3, B, h, c, n)
+    ref = R._linear_attention_core(t[0], t[1], t[2])                          # (B, 128, N)
+    assert rel(out, ref.permute(0, 2, 1).reshape(B * N, 128)) < 3e-6
+
+
+def test_linear_attention_cross():
+    from diffuscene_amd import ops
+    B, N, L = 3, 12, 7
+    q, kv = rnd(B * N, 128, seed=37) * 2, rnd(B * L, 256, seed=38) * 2
+    out = ops.linear_attention(q.to(dev()), kv.to(dev())[:, :128], kv.to(dev())[:, 128:], B, N, L, 32 ** -0.5)
+    qh = q.double().reshape(B, N, 4, 32).permute(0, 2, 3, 1)
+    kh = kv.double()[:, :128].reshape(B, L, 4, 32).permute(0, 2, 3, 1)
+    vh = kv.double()[:, 128:].reshape(B, L, 4, 32).permute(0, 2, 3, 1)
+    ref = R._linear_attention_core(qh, kh, vh).permute(0, 2, 1).reshape(B * N, 128)
+    assert rel(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("B,N", [(3, 80), (4, 12), (1, 160)])
+def test_softmax_attention(B, N):
+    from diffuscene_amd import ops
+    qkv = rnd(B * N, 384, seed=39) * 2
+    d = qkv.to(dev())
+    out = ops.attention(d[:, :128], d[:, 128:256], d[:, 256:], B, N, 32 ** -0.5)
+    t = qkv.double().reshape(B, N, 3, 4, 32).permute(2, 0, 3, 4, 1)          # (3, B, h, d, n)
+    q, k, v = t[0] * 32 ** -0.5, t[1], t[2]
+    attn = torch.einsum("bhdi,bhdj->bhij", q, k).softmax(-1)
+    ref = torch.einsum("bhij,bhdj->bhid", attn, v).permute(0, 2, 1, 3).reshape(B * N, 128)
+    assert rel(out, ref) < 3e-6
+
+
+def test_linear_smallk_on_unaligned_slices():
+    from diffuscene_amd import ops
+    M = 77
+    x = rnd(M, 65, seed=40).to(dev())
+    for c0, k, act in ((0, 8, 1), (8, 25, 1), (33, 32, 1), (0, 5, 0)):
+        w, b = rnd(512, k, seed=41 + k), rnd(512, seed=42 + k)
+        y = ops.linear_smallk(x[:, c0:c0 + k], w.to(dev()), b.to(dev()), act_out=act)
+        z = x[:, c0:c0 + k].double().cpu() @ w.double().T + b.double()
+        assert rel(y, F.gelu(z) if act else z) < 2e-6
+
+
+def test_time_embedding_table_is_bit_exact_and_fallback_close():
+    from diffuscene_amd import ops
+    half = 256
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    arg = torch.arange(1000)[:, None] * freq[None, :]
+    table = torch.cat((arg.sin(), arg.cos()), -1)
+    t = torch.tensor([0, 1, 17, 999, 1500], dtype=torch.int64)
+    out = ops.time_embedding(t.to(dev()), 512, table.to(dev()), freq.to(dev())).cpu()
+    ref = R.sinusoidal_embedding(t, 512)
+    assert torch.equal(out[:4], ref[:4])
+    assert float((out[4] - ref[4]).abs().max()) < 5e-4       # beyond the table: device sinf/cosf of the same fp32 argument
+
+
+def test_diffusion_elementwise_bit_exact():
+    from diffuscene_amd import ops
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    B, N, C = 6, 21, 65
+    x0, noise, v = rnd(B, N, C, seed=50), torch.randn(B, N, C, generator=torch.Generator().manual_seed(1)), rnd(B, N, C, seed=51) * 2
+    t = torch.tensor([0, 1, 500, 998, 999, 0], dtype=torch.int64)
+    d = {k: tb[k].to(dev()) for k in tb}
+    sigma = torch.exp(0.5 * tb["posterior_log_variance_clipped"]).to(dev())
+    xt, vt = ops.q_sample(x0.to(dev()), noise.to(dev()), t.to(dev()), d["sqrt_alphas_cumprod"],
+                          d["sqrt_one_minus_alphas_cumprod"], want_v=True)
+    assert torch.equal(xt.cpu(), R.q_sample(tb, x0, t, noise))
+    assert torch.equal(vt.cpu(), R.predict_v(tb, x0, t, noise))
+    for clip in (True, False):
+        for mt, name, ca, cb in ((2, "v", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"),
+                                 (0, "eps", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"), (1, "x0", None, None)):
+            out = ops.p_sample(x0.to(dev()), v.to(dev()), noise.to(dev()), t.to(dev()), d[ca] if ca else None,
+                               d[cb] if cb else None, d["posterior_mean_coef1"], d["posterior_mean_coef2"], sigma, mt, clip)
+            ref = R.p_sample_step(tb, x0, t, v, noise, clip, name)
+            assert torch.equal(out.cpu(), ref), (name, clip, float((out.cpu() - ref).abs().max()))
+    x = rnd(B, N, C, seed=52).to(dev())
+    part, pn = rnd(B, 4, C, seed=53), rnd(B, 4, C, seed=54)
+    keep = x.clone()
+    ops.complete_overwrite(x, part.to(dev()), pn.to(dev()), t.to(dev()), d["sqrt_alphas_cumprod"], d["sqrt_one_minus_alphas_cumprod"])
+    assert torch.equal(x[:, :4].cpu(), R.q_sample(tb, part, t, pn)) and torch.equal(x[:, 4:], keep[:, 4:])
+    tt = t.to(dev()).clone()
+    ops.add_scalar_i64(tt, -1)
+    assert torch.equal(tt.cpu(), t - 1)
+
+
+def test_bad_arguments_are_rejected_not_clamped():
+    from diffuscene_amd import ops
+    a, w = torch.zeros(8, 48, device=dev()), torch.zeros(8, 48, device=dev())
+    with pytest.raises(RuntimeError, match="DSC_EINVAL"):
+        ops.gemm(a, w)                                    # K not a multiple of 32
+    x = torch.zeros(2 * 200, 512, device=dev())
+    wz = torch.zeros(512, 512, device=dev())
+    v = torch.zeros(512, device=dev())
+    with pytest.raises(RuntimeError, match="DSC_ERANGE"):
+        ops.gemm_gn_silu(x, wz, v, v, v, 200)            # more than 160 objects per scene

@@ -1,0 +1,162 @@
+"""CPU: host-side logic of the product package -- no kernel is ever executed here.
+* the C-ABI library loads and exports every function include/diffuscene_hip.h declares;
+* state_dict layout == reference layout (golden key list), checkpoints round-trip;
+* schedule tables are bit-identical to the reference's (golden);
+* the product refuses to compute on CPU tensors (no fallback);
+* RNG draw order / noise_fn protocol of the loops, checked with a recording fake kernel backend."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as W
+from oracle.make_golden import CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diffuscene_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "diffuscene_hip.h")).read()
+    declared = set(re.findall(r"^\s*int\s+(dsc_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), "%s declared in the header but not exported" % name
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.dsc_version() >= 100
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_state_dict_layout_is_the_reference_layout(golden_dir, name):
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))[name]
+    net = Unet1D(**CASES[name][0])
+    assert {k: list(v.shape) for k, v in net.state_dict().items()} == {k: s for k, s in keys}
+    sd = W.synth_state_dict(CASES[name][0])
+    net.load_state_dict(sd, strict=True)                      # a reference checkpoint loads unchanged
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_schedule_tables_bit_identical_to_reference(golden_dir):
+    from diffuscene_amd.networks.diffusion_ddpm import GaussianDiffusion, get_betas
+    g = np.load(os.path.join(golden_dir, "schedule_v_T1000.npz"))
+    d = GaussianDiffusion({}, get_betas("linear", 1e-4, 0.02, 1000), "mse", "v", "fixedsmall", True, False, None)
+    for k in g.files:
+        assert np.array_equal(getattr(d, k).numpy(), g[k]), k
+    with pytest.raises(NotImplementedError):
+        get_betas("cosine", 1e-4, 0.02, 10)
+
+
+def test_no_cpu_fallback():
+    from diffuscene_amd import ops
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    net = Unet1D(**W.UNCOND_BEDROOM)
+    x = torch.zeros(1, 12, 62)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        net(x, torch.zeros(1, dtype=torch.int64), None, None)
+    diff = DiffusionPoint(net, dict(objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32), model_mean_type="v")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        diff.diffusion.q_sample(x, torch.zeros(1, dtype=torch.int64), torch.zeros_like(x))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.gemm(torch.zeros(4, 32), torch.zeros(8, 32))
+
+
+def test_unsupported_layouts_fail_loudly():
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    with pytest.raises(NotImplementedError):
+        Unet1D(dim=256, dim_mults=(1, 2, 4, 8))
+
+
+class _FakeOps:
+    """Recording stand-in for diffuscene_amd.ops (TEST DOUBLE, lives in tests/ only)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def p_sample(self, x_t, model_out, noise, t, *a, **k):
+        self.calls.append(("p_sample", int(t[0]), float(noise.flatten()[0])))
+        return x_t
+
+    def complete_overwrite(self, x, partial, noise, t, *a):
+        self.calls.append(("overwrite", int(t[0]), float(noise.flatten()[0])))
+        return x
+
+
+def test_reverse_loop_draw_order(monkeypatch):
+    """x_T first, then per step: (completion: partial noise BEFORE the model call) model call, one p_sample draw --
+    also at t == 0 (diffusion_ddpm.py:345,364,461)."""
+    from diffuscene_amd.networks import diffusion_ddpm as dd
+    fake = _FakeOps()
+    monkeypatch.setattr(dd, "ops", fake)
+    d = dd.GaussianDiffusion({}, dd.get_betas("linear", 1e-4, 0.02, 3), "mse", "v", "fixedsmall", True, False, None)
+    monkeypatch.setattr(d, "tables", lambda device: {n: getattr(d, n) for n in d._TABLE_NAMES})
+    events = []
+    counter = [0]
+
+    def noise_fn(size=None, dtype=None, device=None):
+        counter[0] += 1
+        events.append(("draw", counter[0], tuple(size)))
+        return torch.full(size, float(counter[0]))
+
+    def denoise(x, t, c, cc):
+        events.append(("model", int(t[0])))
+        return x
+
+    d.p_sample_loop(denoise, (2, 4, 5), "cpu", None, None, noise_fn=noise_fn)
+    assert [e[0] for e in events] == ["draw", "model", "draw", "model", "draw", "model", "draw"]
+    assert [c for c in fake.calls] == [("p_sample", 2, 2.0), ("p_sample", 1, 3.0), ("p_sample", 0, 4.0)]
+    events.clear(); fake.calls.clear(); counter[0] = 0
+    d.p_sample_loop_complete(denoise, (2, 4, 5), "cpu", None, None, noise_fn=noise_fn,
+                             partial_boxes=torch.zeros(2, 1, 5))
+    assert [e[0] for e in events] == ["draw"] + ["draw", "model", "draw"] * 3
+    assert [c[0] for c in fake.calls] == ["overwrite", "p_sample"] * 3
+    assert events[1][2] == (2, 1, 5) and events[3][2] == (2, 4, 5)
+
+
+def test_scene_layout_wrapper_state_dict_and_postfilter():
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 62, "latent_dim": 0,
+           "room_mask_condition": False, "sample_num_points": 12, "objectness_dim": 0, "objfeat_dim": 32,
+           "class_dim": 22, "angle_dim": 2, "learnable_embedding": True, "instance_condition": True,
+           "instance_emb_dim": 128,
+           "diffusion_kwargs": dict(schedule_type="linear", beta_start=1e-4, beta_end=0.02, time_num=1000,
+                                    loss_type="mse", model_mean_type="v", model_var_type="fixedsmall",
+                                    loss_separate=True, loss_iou=False, train_stats_file=None),
+           "net_kwargs": dict(W.UNCOND_BEDROOM)}
+    m = DiffusionSceneLayout_DDPM(23, None, cfg)
+    keys = set(m.state_dict().keys())
+    assert "positional_embedding" in keys
+    assert {"diffusion.model." + k for k in W.unet1d_param_spec(**W.UNCOND_BEDROOM)} == keys - {"positional_embedding"}
+    cond = m._instance_condition(5, torch.device("cpu"))
+    assert cond.shape == (5, 12, 128) and cond.stride(0) == 0       # broadcast view, no (B,N,128) copy
+    s = torch.zeros(2, 12, 62)
+    s[:, :, 8 + 21] = 1.0          # all slots "empty" ...
+    s[0, [1, 4], 8 + 21] = -1.0    # ... except slots 1 and 4 of batch row 0
+    s[:, :, 0] = torch.arange(12.)[None]
+    out = m.delete_empty_from_network_samples(s)
+    assert out["translations"].shape == (2, 2, 3) and out["translations"][1, :, 0].tolist() == [1.0, 4.0]
+    assert out["class_labels"].shape == (2, 2, 21) and out["objfeats"].shape == (2, 2, 32)
+    assert m.delete_empty_from_network_samples(s, keep_empty=True)["sizes"].shape == (2, 12, 3)
+
+
+def test_install_as_scene_synthesis():
+    import sys
+    import diffuscene_amd
+    saved = {k: v for k, v in sys.modules.items() if k.startswith("scene_synthesis")}
+    try:
+        diffuscene_amd.install_as_scene_synthesis()
+        from scene_synthesis.networks import build_network, optimizer_factory, schedule_factory, adjust_learning_rate  # noqa
+        from scene_synthesis.stats_logger import StatsLogger, WandB  # noqa
+        from scene_synthesis.networks.diffusion_ddpm import GaussianDiffusion  # noqa
+        sched = schedule_factory({"schedule": "step", "lr": 2e-4, "lr_step": 10, "lr_decay": 0.5})
+        assert sched.get_learning_rate(25) == 2e-4 * 0.25
+    finally:
+        for k in [k for k in sys.modules if k.startswith("scene_synthesis")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
