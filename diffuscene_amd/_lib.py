@@ -38,11 +38,16 @@ class GemmArgs(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
         ("tokens_per_scene", C.c_int32),
         ("scale_shift", C.c_void_p), ("ld_ss", C.c_int64), ("ss_mode", C.c_int32),
+        ("preact", C.c_void_p), ("ld_preact", C.c_int64),
     ]
 
 
 class WsItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+class WsBwdItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dw_std", C.c_void_p), ("dw", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every function declared in include/diffuscene_hip.h
@@ -66,6 +71,21 @@ SIGNATURES = {
     "dsc_p_sample_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                    c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "dsc_add_scalar_i64": (C.c_int, [c_i64p, C.c_int32, C.c_int64, C.c_void_p]),
+    "dsc_gemm_tn_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p,
+                                  C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
+    "dsc_gemm_tn_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
+    "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
+                                      c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_weight_standardize_bwd_f32": (C.c_int, [C.POINTER(WsBwdItem), C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_layernorm_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_linear_attention_bwd_f32": (C.c_int, [c_f32p, C.c_int64] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                                                          C.c_void_p]),
+    "dsc_attention_bwd_f32": (C.c_int, [c_f32p, C.c_int64] * 7 + [C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "dsc_activation_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dsc_transpose_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_complete_overwrite_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_int32, C.c_void_p]),
 }

@@ -158,6 +158,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const dsc_gemm_args p, con
     const bool vec_r = res && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0) && ((p.n & 3) == 0);
 
     if constexpr (GN) {
+        if (p.preact) {                   // training: keep the pre-norm conv output for the backward pass
+            float* zp = p.preact + (int64_t)z * p.sy;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int tl = (wm * TM + tm) * 32 + l31;
+                if (tl >= rows_here) continue;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = col0 + (wn * TN + tn) * 32 + 8 * q + 4 * half;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[tm][tn][4 * q + e];
+                        *reinterpret_cast<f32x4*>(zp + (row0 + tl) * p.ld_preact + c) = v;
+                    }
+            }
+        }
         constexpr int G = BN / 64;        // GroupNorm groups covered by this block
         constexpr int CT = BN / 32;       // 32-channel tiles in the block
         float* P = smem;                  // [CT][BM] per-token partial sums
@@ -376,6 +394,7 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
     if (a->n % 128) return DSC_EINVAL;
     if (a->act_in != DSC_ACT_NONE) return DSC_EINVAL;
     if (!dsc_aligned16(a->gamma) || !dsc_aligned16(a->beta)) return DSC_EALIGN;
+    if (a->preact && (!dsc_aligned16(a->preact) || (a->ld_preact & 3))) return DSC_EALIGN;
     if (a->ss_mode != DSC_SS_NONE) {
         if (!a->scale_shift) return DSC_EINVAL;
         if (!dsc_aligned16(a->scale_shift) || (a->ld_ss & 3)) return DSC_EALIGN;

@@ -1,0 +1,828 @@
+// Backward kernels of the DDPM training step (reference: autograd through denoise_net.py; here hand-written).
+//
+//   gemm_tn_kernel        dW[n][k] = sum_m dY[m][n] * A[m][k]   (weight gradients; fp32 MFMA, split over tokens)
+//   reduce_slabs_kernel   deterministic second stage of every split reduction
+//   colsum_kernel         bias / affine gradients: column sums over tokens
+//   gn_silu_bwd_kernel    backward of the fused GroupNorm + (scale+1,shift) + SiLU epilogue, one (scene, group) per block
+//   ws_bwd_kernel         backward of weight standardisation
+//   layernorm_bwd_kernel  backward of the channel LayerNorm (+ gain gradient partials)
+//   linear_attention_bwd_kernel / attention_bwd_kernel   one (scene, head) per block
+//   act_bwd_kernel, transpose_kernel
+// Input gradients (dA = dY . W) reuse the forward NT kernel (gemm_mfma.hip) on transposed weights.
+#include "dsc_common.h"
+
+namespace {
+
+// =====================================================================================================
+// TN GEMM: out[j = n][i = k] = sum_m dy[m][n] * a[m][k].   MFMA A operand = 32 input channels (i), B operand = 32
+// output channels (j), reduction over tokens m two at a time.  Both tiles are staged exactly as they lie in HBM
+// ([m][channel], channel contiguous), fragments are ds_read_b32 along the channel -> conflict-free, no transposes.
+// =====================================================================================================
+constexpr int TN_BK = 32;      // tokens per staged tile
+constexpr int TN_LD = 132;     // 128 + 4 pad floats
+
+struct TnArgs {
+    const float* a1; long lda1; int k1;
+    const float* a2; long lda2; int k2;       // optional second channel segment
+    const float* dy; long ldd;
+    float* out; long ldo;                     // [n][k1+k2] (or slab s at out + s*slab)
+    long slab;                                // elements between split slabs (0 when splits == 1)
+    int m, n, kvalid;                         // kvalid: columns >= kvalid are not stored (padded small-K inputs)
+    int chunk;                                // tokens per split (multiple of 32)
+    int ktiles;                               // number of 128-wide k tiles
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int it = blockIdx.x % p.ktiles, jt = blockIdx.x / p.ktiles;
+    const int i0 = it * 128, j0 = jt * 128;
+    const int split = blockIdx.y;
+    const long m_begin = (long)split * p.chunk;
+    const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
+
+    const float* ab;
+    long lda;
+    int ic;          // column of this k tile inside its segment
+    int kseg;        // columns available in the segment
+    if (i0 < p.k1) { ab = p.a1; lda = p.lda1; ic = i0; kseg = p.k1; }
+    else           { ab = p.a2; lda = p.lda2; ic = i0 - p.k1; kseg = p.k2; }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    f32x4 ar[4], br[4];
+    auto load_tile = [&](long m0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + 256 * q;
+            const int r = f >> 5, c4 = (f & 31) * 4;
+            const long m = m0 + r;
+            if (m < m_end && ic + c4 < kseg) ar[q] = *reinterpret_cast<const f32x4*>(ab + m * lda + ic + c4);
+            else                             ar[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < m_end && j0 + c4 < p.n)  br[q] = *reinterpret_cast<const f32x4*>(p.dy + m * p.ldd + j0 + c4);
+            else                             br[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + 256 * q;
+            const int r = f >> 5, c4 = (f & 31) * 4;
+            *reinterpret_cast<f32x4*>(As + r * TN_LD + c4) = ar[q];
+            *reinterpret_cast<f32x4*>(Bs + r * TN_LD + c4) = br[q];
+        }
+    };
+
+    if (m_begin < m_end) {
+        load_tile(m_begin);
+        for (long m0 = m_begin; m0 < m_end; m0 += TN_BK) {
+            store_tile();
+            __syncthreads();
+            if (m0 + TN_BK < m_end) load_tile(m0 + TN_BK);
+#pragma unroll
+            for (int s = 0; s < TN_BK / 2; ++s) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[a] = As[(2 * s + half) * TN_LD + (wi * 2 + a) * 32 + l31];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[b] = Bs[(2 * s + half) * TN_LD + (wj * 2 + b) * 32 + l31];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    float* out = p.out + (long)split * p.slab;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + (wj * 2 + b) * 32 + l31;          // output row (n)
+        if (j >= p.n) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + (wi * 2 + a) * 32 + 8 * q + 4 * half;   // output column (k), 4 consecutive
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[a][b][4 * q + e];
+            }
+    }
+}
+
+// out[i] = sum_s slabs[s][i]   (deterministic order)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long slab, int nslab, float* __restrict__ out,
+                                    long count) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[(long)k * slab + i];
+        out[i] = s;
+    }
+}
+
+// partial[s][c] = sum over rows of chunk s of x[r][c];  block = 64 columns x one chunk
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, int m, int n, int chunk,
+                                                    float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rq = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * chunk;
+    const long r1 = (r0 + chunk < m) ? r0 + chunk : m;
+    float s = 0.f;
+    if (c < n)
+        for (long r = r0 + rq; r < r1; r += 4) s += x[r * ldx + c];
+    red[rq][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rq == 0 && c < n) partial[(long)blockIdx.y * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                                              (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// =====================================================================================================
+// Backward of the fused GroupNorm + (scale+1, shift) + SiLU epilogue.  Block = (scene b, group g): 64 channels x N tokens.
+//   z: pre-norm conv output (saved by the forward), dy: gradient of the block output.
+//   dz = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)),  xh = (z - mu) * rstd, dxh = dgh * gamma,
+//   dgh = du * (1 + scale), du = dy * silu'(u), u = (gamma * xh + beta) * (1 + scale) + shift.
+// Per-channel token sums (dgamma, dbeta, dbias and, for per-scene conditioning, dscale/dshift) are written per scene
+// and reduced over scenes by colsum_kernel: deterministic, no atomics.
+// =====================================================================================================
+struct GnBwdArgs {
+    const float* z; long ldz;
+    const float* dy; long ldy;
+    const float* gamma; const float* beta;
+    const float* ss; long ld_ss; int ss_mode;
+    float* dz; long lddz;
+    float* dgamma_p; float* dbeta_p; float* dbias_p;     // [scenes][C]
+    float* dss; long ld_dss;                              // per-scene: [scenes][2C]; per-token/slot: [M][2C]
+    int n_tok, C; float eps;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const GnBwdArgs p) {
+    __shared__ float red[4];
+    __shared__ float csum[6][4][64];
+    const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
+    const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    const int c = g * 64 + cl;
+    const int N = p.n_tok;
+    const long tok0 = (long)b * N;
+    const float inv_cnt = 1.0f / (64.0f * (float)N);
+    // statistics of the group (two passes, as the forward)
+    float s = 0.f;
+    for (int j = tq; j < N; j += 4) s += p.z[(tok0 + j) * p.ldz + c];
+    const float mu = block_sum(s, red) * inv_cnt;
+    s = 0.f;
+    for (int j = tq; j < N; j += 4) { const float d = p.z[(tok0 + j) * p.ldz + c] - mu; s += d * d; }
+    const float rs = 1.0f / sqrtf(block_sum(s, red) * inv_cnt + p.eps);
+    const float ga = p.gamma[c], be = p.beta[c];
+
+    auto ss_row = [&](long tok) -> const float* {
+        if (p.ss_mode == DSC_SS_PER_TOKEN) return p.ss + tok * p.ld_ss;
+        if (p.ss_mode == DSC_SS_PER_SCENE) return p.ss + (long)b * p.ld_ss;
+        if (p.ss_mode == DSC_SS_PER_SLOT) return p.ss + (tok - tok0) * p.ld_ss;
+        return nullptr;
+    };
+    // pass 1: group means of dxh and dxh*xh, per-channel sums
+    float S1 = 0.f, S2 = 0.f, Gg = 0.f, Gb = 0.f, Gsc = 0.f, Gsh = 0.f;
+    for (int j = tq; j < N; j += 4) {
+        const long tok = tok0 + j;
+        const float xh = (p.z[tok * p.ldz + c] - mu) * rs;
+        const float gh = ga * xh + be;
+        float s1 = 1.0f, sh = 0.f;
+        const float* sr = ss_row(tok);
+        if (sr) { s1 = 1.0f + sr[c]; sh = sr[p.C + c]; }
+        const float u = gh * s1 + sh;
+        const float sig = 1.0f / (1.0f + expf(-u));
+        const float du = p.dy[tok * p.ldy + c] * (sig * (1.0f + u * (1.0f - sig)));
+        const float dgh = du * s1;
+        const float dxh = dgh * ga;
+        S1 += dxh; S2 += dxh * xh; Gg += dgh * xh; Gb += dgh; Gsc += du * gh; Gsh += du;
+        if (p.dss && p.ss_mode != DSC_SS_PER_SCENE && sr) {
+            p.dss[tok * p.ld_dss + c] = du * gh;
+            p.dss[tok * p.ld_dss + p.C + c] = du;
+        }
+    }
+    const float m1 = block_sum(S1, red) * inv_cnt;
+    const float m2 = block_sum(S2, red) * inv_cnt;
+    // pass 2: dz and its per-channel sum (bias gradient)
+    float Gz = 0.f;
+    for (int j = tq; j < N; j += 4) {
+        const long tok = tok0 + j;
+        const float xh = (p.z[tok * p.ldz + c] - mu) * rs;
+        const float gh = ga * xh + be;
+        float s1 = 1.0f, sh = 0.f;
+        const float* sr = ss_row(tok);
+        if (sr) { s1 = 1.0f + sr[c]; sh = sr[p.C + c]; }
+        const float u = gh * s1 + sh;
+        const float sig = 1.0f / (1.0f + expf(-u));
+        const float du = p.dy[tok * p.ldy + c] * (sig * (1.0f + u * (1.0f - sig)));
+        const float dxh = du * s1 * ga;
+        const float dzv = rs * (dxh - m1 - xh * m2);
+        p.dz[tok * p.lddz + c] = dzv;
+        Gz += dzv;
+    }
+    csum[0][tq][cl] = Gg; csum[1][tq][cl] = Gb; csum[2][tq][cl] = Gz; csum[3][tq][cl] = Gsc; csum[4][tq][cl] = Gsh;
+    __syncthreads();
+    if (tq == 0) {
+        const long o = (long)b * p.C + c;
+        p.dgamma_p[o] = (csum[0][0][cl] + csum[0][1][cl]) + (csum[0][2][cl] + csum[0][3][cl]);
+        p.dbeta_p[o] = (csum[1][0][cl] + csum[1][1][cl]) + (csum[1][2][cl] + csum[1][3][cl]);
+        p.dbias_p[o] = (csum[2][0][cl] + csum[2][1][cl]) + (csum[2][2][cl] + csum[2][3][cl]);
+        if (p.dss && p.ss_mode == DSC_SS_PER_SCENE) {
+            p.dss[(long)b * p.ld_dss + c] = (csum[3][0][cl] + csum[3][1][cl]) + (csum[3][2][cl] + csum[3][3][cl]);
+            p.dss[(long)b * p.ld_dss + p.C + c] = (csum[4][0][cl] + csum[4][1][cl]) + (csum[4][2][cl] + csum[4][3][cl]);
+        }
+    }
+}
+
+// =====================================================================================================
+// weight standardisation backward, one block per weight row (batched like the forward)
+// =====================================================================================================
+struct WsBwdItem { const float* w; const float* dwh; float* dw; int rows; int cols; };
+struct WsBwdBatch { WsBwdItem it[DSC_WS_MAX]; };
+
+__global__ __launch_bounds__(256) void ws_bwd_kernel(const WsBwdBatch bch, const float eps) {
+    __shared__ float red[4];
+    const WsBwdItem it = bch.it[blockIdx.y];
+    const int row = blockIdx.x;
+    if (row >= it.rows) return;
+    const float* w = it.w + (long)row * it.cols;
+    const float* g = it.dwh + (long)row * it.cols;
+    float* o = it.dw + (long)row * it.cols;
+    constexpr int MAXE = 8;
+    float v[MAXE], gv[MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = (c < it.cols) ? w[c] : 0.f;
+        gv[i] = (c < it.cols) ? g[c] : 0.f;
+        s += v[i];
+    }
+    const float inv = 1.0f / (float)it.cols;
+    const float mean = block_sum(s, red) * inv;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        const float d = (c < it.cols) ? v[i] - mean : 0.f;
+        s2 += d * d;
+    }
+    const float rs = 1.0f / sqrtf(block_sum(s2, red) * inv + eps);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < it.cols) { v[i] = (v[i] - mean) * rs; a1 += gv[i]; a2 += gv[i] * v[i]; }
+    }
+    const float m1 = block_sum(a1, red) * inv;
+    const float m2 = block_sum(a2, red) * inv;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < it.cols) o[c] = rs * (gv[i] - m1 - v[i] * m2);
+    }
+}
+
+// =====================================================================================================
+// channel LayerNorm backward (d = 512): wave per row, block-strided over rows, gain-gradient partial per block
+// =====================================================================================================
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long ldx,
+                                                           const float* __restrict__ g,
+                                                           const float* __restrict__ dy, long ldy,
+                                                           float* __restrict__ dx, long lddx,
+                                                           float* __restrict__ dg_partial, int m, float eps) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(g + lane * 4);
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(g + 256 + lane * 4);
+    float dga[4] = {0.f, 0.f, 0.f, 0.f}, dgb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * 4 + wave; row < m; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * ldx;
+        const float* dr = dy + row * ldy;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xr + lane * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xr + 256 + lane * 4);
+        const f32x4 da = *reinterpret_cast<const f32x4*>(dr + lane * 4);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(dr + 256 + lane * 4);
+        float s = (a[0] + a[1]) + (a[2] + a[3]) + (b[0] + b[1]) + (b[2] + b[3]);
+        const float mean = wave_sum(s) * (1.0f / 512.0f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float u = a[e] - mean, w = b[e] - mean; s2 += u * u + w * w; }
+        const float rs = 1.0f / sqrtf(wave_sum(s2) * (1.0f / 512.0f) + eps);
+        float xa[4], xb[4], ha[4], hb[4];
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xa[e] = (a[e] - mean) * rs; xb[e] = (b[e] - mean) * rs;
+            ha[e] = da[e] * ga[e]; hb[e] = db[e] * gb[e];
+            t1 += ha[e] + hb[e];
+            t2 += ha[e] * xa[e] + hb[e] * xb[e];
+            dga[e] += da[e] * xa[e]; dgb[e] += db[e] * xb[e];
+        }
+        const float m1 = wave_sum(t1) * (1.0f / 512.0f);
+        const float m2 = wave_sum(t2) * (1.0f / 512.0f);
+        f32x4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oa[e] = rs * (ha[e] - m1 - xa[e] * m2);
+            ob[e] = rs * (hb[e] - m1 - xb[e] * m2);
+        }
+        float* o = dx + row * lddx;
+        *reinterpret_cast<f32x4*>(o + lane * 4) = oa;
+        *reinterpret_cast<f32x4*>(o + 256 + lane * 4) = ob;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][lane * 4 + e] = dga[e]; red[wave][256 + lane * 4 + e] = dgb[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256)
+        dg_partial[(long)blockIdx.x * 512 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// =====================================================================================================
+// linear attention backward, block = (scene, head), dynamic LDS: Ks, Vs, DK [nk][33]; Qs, DO [nq][33]; ctx, dctx [32][33]
+// =====================================================================================================
+constexpr int HP = 33;
+
+__global__ __launch_bounds__(128) void linear_attention_bwd_kernel(
+        const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk, const float* __restrict__ v, long ldv,
+        const float* __restrict__ dout, long ldo, float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
+        float* __restrict__ dv, long lddv, int nq, int nk, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ks = lds;
+    float* Vs = Ks + nk * HP;
+    float* DK = Vs + nk * HP;
+    float* Qs = DK + nk * HP;
+    float* DO = Qs + nq * HP;
+    float* ctx = DO + nq * HP;
+    float* dctx = ctx + 32 * HP;
+    float* cvec = dctx + 32 * HP;       // [32] per-channel scratch
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int tid = threadIdx.x;
+    const float* kb = k + (long)b * nk * ldk + h * 32;
+    const float* vb = v + (long)b * nk * ldv + h * 32;
+    for (int f = tid; f < nk * 8; f += 128) {
+        const int j = f >> 3, c4 = (f & 7) * 4;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)j * ldk + c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long)j * ldv + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { Ks[j * HP + c4 + e] = kv[e]; Vs[j * HP + c4 + e] = vv[e]; }
+    }
+    __syncthreads();
+    {   // ks = softmax over tokens (normalised in place)
+        const int d = tid >> 2, part = tid & 3;
+        float mx = -INFINITY;
+        for (int j = part; j < nk; j += 4) mx = fmaxf(mx, Ks[j * HP + d]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sm = 0.f;
+        for (int j = part; j < nk; j += 4) { const float e = expf(Ks[j * HP + d] - mx); Ks[j * HP + d] = e; sm += e; }
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        const float inv = 1.0f / sm;
+        for (int j = part; j < nk; j += 4) Ks[j * HP + d] *= inv;
+    }
+    // qs = softmax over channels * scale; keep the probabilities' row data in Qs (scaled) and load dout
+    for (int i = tid; i < nq; i += 128) {
+        const float* qr = q + ((long)b * nq + i) * ldq + h * 32;
+        const float* dr = dout + ((long)b * nq + i) * ldo + h * 32;
+        float qv[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(qr + c * 4);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dr + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qv[c * 4 + e] = t4[e]; DO[i * HP + c * 4 + e] = d4[e]; }
+        }
+        float mx = qv[0];
+#pragma unroll
+        for (int d = 1; d < 32; ++d) mx = fmaxf(mx, qv[d]);
+        float sm = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qv[d] = expf(qv[d] - mx); sm += qv[d]; }
+        const float inv = 1.0f / sm;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) Qs[i * HP + d] = qv[d] * inv * scale;
+    }
+    __syncthreads();
+    {   // ctx[d][e] = sum_j ks[j][d] v[j][e];  dctx[d][e] = sum_i qs[i][d] dout[i][e]
+        const int d = tid >> 2, e0 = (tid & 3) * 8;
+        float a[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = 0.f; g[e] = 0.f; }
+        for (int j = 0; j < nk; ++j) {
+            const float kd = Ks[j * HP + d];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += kd * Vs[j * HP + e0 + e];
+        }
+        for (int i = 0; i < nq; ++i) {
+            const float qd = Qs[i * HP + d];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] += qd * DO[i * HP + e0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ctx[d * HP + e0 + e] = a[e]; dctx[d * HP + e0 + e] = g[e]; }
+    }
+    __syncthreads();
+    // dq: dqs[d] = sum_e dout[e] ctx[d][e]; softmax backward with p = qs / scale
+    for (int i = tid; i < nq; i += 128) {
+        float dqs[32];
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) s += DO[i * HP + e] * ctx[d * HP + e];
+            dqs[d] = s;
+            dot += s * Qs[i * HP + d];          // sum_d dqs[d] * (scale * p[d])
+        }
+        float* o = dq + ((long)b * nq + i) * lddq + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 t4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = c * 4 + e;
+                t4[e] = Qs[i * HP + d] * (dqs[d] - dot / scale);   // p*scale*(dqs - sum_d' dqs p), Qs = p*scale
+            }
+            *reinterpret_cast<f32x4*>(o + c * 4) = t4;
+        }
+    }
+    // dks / dv per key token
+    for (int j = tid; j < nk; j += 128) {
+        float dvv[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) dvv[e] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            const float kd = Ks[j * HP + d];
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) { s += dctx[d * HP + e] * Vs[j * HP + e]; dvv[e] += kd * dctx[d * HP + e]; }
+            DK[j * HP + d] = s;
+        }
+        float* o = dv + ((long)b * nk + j) * lddv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 t4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t4[e] = dvv[c * 4 + e];
+            *reinterpret_cast<f32x4*>(o + c * 4) = t4;
+        }
+    }
+    __syncthreads();
+    {   // softmax-over-tokens backward: dk[j][d] = ks[j][d] * (dks[j][d] - sum_j' dks[j'][d] ks[j'][d])
+        const int d = tid >> 2, part = tid & 3;
+        float s = 0.f;
+        for (int j = part; j < nk; j += 4) s += DK[j * HP + d] * Ks[j * HP + d];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (part == 0) cvec[d] = s;
+    }
+    __syncthreads();
+    for (int f = tid; f < nk * 8; f += 128) {
+        const int j = f >> 3, c4 = (f & 7) * 4;
+        f32x4 t4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[e] = Ks[j * HP + c4 + e] * (DK[j * HP + c4 + e] - cvec[c4 + e]);
+        *reinterpret_cast<f32x4*>(dk + ((long)b * nk + j) * lddk + h * 32 + c4) = t4;
+    }
+}
+
+// =====================================================================================================
+// softmax attention backward, block = (scene, head); phase 1 thread per query, phase 2 thread per key (recompute p)
+// dynamic LDS: Qs (scaled), Ks, Vs, DO [n][33]; row stats mx, inv_sum, D [n]
+// =====================================================================================================
+__global__ __launch_bounds__(192) void attention_bwd_kernel(
+        const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk, const float* __restrict__ v, long ldv,
+        const float* __restrict__ dout, long ldo, float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
+        float* __restrict__ dv, long lddv, int n, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Qs = lds;
+    float* Ks = Qs + n * HP;
+    float* Vs = Ks + n * HP;
+    float* DO = Vs + n * HP;
+    float* rmx = DO + n * HP;
+    float* rinv = rmx + n;
+    float* rD = rinv + n;
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int tid = threadIdx.x;
+    for (int f = tid; f < n * 8; f += 192) {
+        const int j = f >> 3, c4 = (f & 7) * 4;
+        const long row = (long)b * n + j;
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(q + row * ldq + h * 32 + c4);
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(k + row * ldk + h * 32 + c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(v + row * ldv + h * 32 + c4);
+        const f32x4 dv4 = *reinterpret_cast<const f32x4*>(dout + row * ldo + h * 32 + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Qs[j * HP + c4 + e] = qv[e] * scale; Ks[j * HP + c4 + e] = kv[e];
+            Vs[j * HP + c4 + e] = vv[e]; DO[j * HP + c4 + e] = dv4[e];
+        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const int i = tid;
+        float qv[32], dov[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qv[d] = Qs[i * HP + d]; dov[d] = DO[i * HP + d]; }
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s += qv[d] * Ks[j * HP + d];
+            mx = fmaxf(mx, s);
+        }
+        float sm = 0.f, Dn = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += qv[d] * Ks[j * HP + d]; dp += dov[d] * Vs[j * HP + d]; }
+            const float pj = expf(s - mx);
+            sm += pj;
+            Dn += pj * dp;
+        }
+        const float inv = 1.0f / sm;
+        const float Di = Dn * inv;               // sum_j p_ij dP_ij
+        rmx[i] = mx; rinv[i] = inv; rD[i] = Di;
+        float dqv[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dqv[d] = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += qv[d] * Ks[j * HP + d]; dp += dov[d] * Vs[j * HP + d]; }
+            const float ds = expf(s - mx) * inv * (dp - Di);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dqv[d] += ds * Ks[j * HP + d];
+        }
+        float* o = dq + ((long)b * n + i) * lddq + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 t4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t4[e] = dqv[c * 4 + e] * scale;
+            *reinterpret_cast<f32x4*>(o + c * 4) = t4;
+        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const int j = tid;
+        float kv[32], vv[32], dkv[32], dvv[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { kv[d] = Ks[j * HP + d]; vv[d] = Vs[j * HP + d]; dkv[d] = 0.f; dvv[d] = 0.f; }
+        for (int i = 0; i < n; ++i) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { s += Qs[i * HP + d] * kv[d]; dp += DO[i * HP + d] * vv[d]; }
+            const float pij = expf(s - rmx[i]) * rinv[i];
+            const float ds = pij * (dp - rD[i]);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { dkv[d] += ds * Qs[i * HP + d]; dvv[d] += pij * DO[i * HP + d]; }
+        }
+        float* ok = dk + ((long)b * n + j) * lddk + h * 32;
+        float* ov = dv + ((long)b * n + j) * lddv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 a4, b4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a4[e] = dkv[c * 4 + e]; b4[e] = dvv[c * 4 + e]; }
+            *reinterpret_cast<f32x4*>(ok + c * 4) = a4;
+            *reinterpret_cast<f32x4*>(ov + c * 4) = b4;
+        }
+    }
+}
+
+// dx = dy * act'(x)
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                               long count, int act) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) {
+        const float xv = x[i];
+        float d;
+        if (act == DSC_ACT_GELU) {
+            const float cdf = 0.5f * (1.0f + erff(xv * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * xv * xv);
+            d = cdf + xv * pdf;
+        } else if (act == DSC_ACT_SILU) {
+            const float sig = 1.0f / (1.0f + expf(-xv));
+            d = sig * (1.0f + xv * (1.0f - sig));
+        } else d = 1.0f;
+        dx[i] = dy[i] * d;
+    }
+}
+
+// out[c][r] = in[r][c], 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                       long ldo, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(long)(r0 + r) * ldi + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = tile[tx][c];
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------- C ABI
+extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const float* a2, int64_t lda2, int32_t k2,
+                               const float* dy, int64_t ldd, float* out, int64_t ldo, int32_t m, int32_t n,
+                               int32_t kvalid, float* workspace, int64_t workspace_floats, dsc_stream_t stream) {
+    if (!a1 || !dy || !out || m < 1 || n < 1 || k1 < 1 || k2 < 0 || (k2 > 0 && !a2)) return DSC_EINVAL;
+    if ((k1 & 3) || (k2 & 3) || (n & 3)) return DSC_EINVAL;
+    if (k2 > 0 && (k1 % 128)) return DSC_EINVAL;                       // a k tile never straddles the segments
+    if (!dsc_aligned16(a1) || (lda1 & 3) || !dsc_aligned16(dy) || (ldd & 3)) return DSC_EALIGN;
+    if (k2 > 0 && (!dsc_aligned16(a2) || (lda2 & 3))) return DSC_EALIGN;
+    const int K = k1 + k2;
+    if (kvalid < 1 || kvalid > K) return DSC_EINVAL;
+    const int ktiles = (K + 127) / 128, ntiles = (n + 127) / 128;
+    int splits = (768 + ktiles * ntiles - 1) / (ktiles * ntiles);
+    const int maxs = (m + 31) / 32;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int chunk = ((m + splits - 1) / splits + 31) / 32 * 32;
+    splits = (m + chunk - 1) / chunk;
+    const long slab = (long)n * ldo;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TnArgs p{a1, (long)lda1, k1, a2, (long)lda2, k2, dy, (long)ldd, out, (long)ldo, 0, m, n, kvalid, chunk, ktiles};
+    if (splits > 1) {
+        if (!workspace || workspace_floats < slab * splits) return DSC_EINVAL;
+        if (ldo != kvalid) return DSC_EINVAL;                          // slab reduction assumes a dense [n][kvalid] output
+        p.out = workspace;
+        p.slab = slab;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ktiles * ntiles, splits), dim3(256), 0, s, p);
+    DSC_LAUNCH_CHECK();
+    if (splits > 1) {
+        long blocks = (slab + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, slab, splits, out, slab);
+        DSC_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int64_t dsc_gemm_tn_workspace_floats(int32_t m, int32_t n, int32_t k) {
+    const int ktiles = (k + 127) / 128, ntiles = (n + 127) / 128;
+    int splits = (768 + ktiles * ntiles - 1) / (ktiles * ntiles);
+    const int maxs = (m + 31) / 32;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int chunk = ((m + splits - 1) / splits + 31) / 32 * 32;
+    splits = (m + chunk - 1) / chunk;
+    return splits > 1 ? (int64_t)n * k * splits : 0;
+}
+
+extern "C" int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,
+                              int64_t workspace_floats, dsc_stream_t stream) {
+    if (!x || !out || m < 1 || n < 1) return DSC_EINVAL;
+    int splits = (m + 255) / 256;
+    if (splits > 64) splits = 64;
+    const int chunk = (m + splits - 1) / splits;
+    splits = (m + chunk - 1) / chunk;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (splits == 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, 1), dim3(256), 0, s, x, (long)ldx, m, n, chunk, out);
+        DSC_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!workspace || workspace_floats < (int64_t)splits * n) return DSC_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, splits), dim3(256), 0, s, x, (long)ldx, m, n, chunk, workspace);
+    DSC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, (long)n, splits, out, (long)n);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy, int64_t ldy, const float* gamma,
+                                   const float* beta, const float* scale_shift, int64_t ld_ss, int32_t ss_mode,
+                                   float* dz, int64_t lddz, float* dgamma_p, float* dbeta_p, float* dbias_p,
+                                   float* dss, int64_t ld_dss, int32_t scenes, int32_t tokens_per_scene, int32_t channels,
+                                   float eps, dsc_stream_t stream) {
+    if (!z || !dy || !gamma || !beta || !dz || !dgamma_p || !dbeta_p || !dbias_p) return DSC_EINVAL;
+    if (scenes < 1 || tokens_per_scene < 1 || channels != 512) return DSC_ERANGE;
+    if (ss_mode != DSC_SS_NONE && !scale_shift) return DSC_EINVAL;
+    GnBwdArgs p{z, (long)ldz, dy, (long)ldy, gamma, beta, ss_mode != DSC_SS_NONE ? scale_shift : nullptr, (long)ld_ss,
+                ss_mode, dz, (long)lddz, dgamma_p, dbeta_p, dbias_p, dss, (long)ld_dss, tokens_per_scene, channels, eps};
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(scenes * 8), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_weight_standardize_bwd_f32(const dsc_ws_bwd_item* items, int32_t count, float eps, dsc_stream_t stream) {
+    if (!items || count < 1 || count > DSC_WS_MAX) return DSC_EINVAL;
+    WsBwdBatch b;
+    int maxrows = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].w || !items[i].dw_std || !items[i].dw || items[i].rows < 1 || items[i].cols < 1) return DSC_EINVAL;
+        if (items[i].cols > 2048) return DSC_ERANGE;
+        b.it[i] = WsBwdItem{items[i].w, items[i].dw_std, items[i].dw, items[i].rows, items[i].cols};
+        if (items[i].rows > maxrows) maxrows = items[i].rows;
+    }
+    hipLaunchKernelGGL(ws_bwd_kernel, dim3(maxrows, count), dim3(256), 0, static_cast<hipStream_t>(stream), b, eps);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_layernorm_bwd_f32(const float* x, int64_t ldx, const float* g, const float* dy, int64_t ldy, float* dx,
+                                     int64_t lddx, float* dg_partial, int32_t partial_rows, int32_t m, int32_t d,
+                                     float eps, dsc_stream_t stream) {
+    if (!x || !g || !dy || !dx || !dg_partial || m < 1 || partial_rows < 1) return DSC_EINVAL;
+    if (d != 512) return DSC_ERANGE;
+    if (!dsc_aligned16(x) || !dsc_aligned16(g) || !dsc_aligned16(dy) || !dsc_aligned16(dx) || (ldx & 3) || (ldy & 3) ||
+        (lddx & 3)) return DSC_EALIGN;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(partial_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, (long)ldx, g, dy, (long)ldy, dx, (long)lddx, dg_partial, m, eps);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_linear_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                            int64_t ldv, const float* dout, int64_t ldo, float* dq, int64_t lddq,
+                                            float* dk, int64_t lddk, float* dv, int64_t lddv, int32_t scenes, int32_t nq,
+                                            int32_t nk, float scale, dsc_stream_t stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || scenes < 1 || nq < 1 || nk < 1) return DSC_EINVAL;
+    if (nq > 160 || nk > 160) return DSC_ERANGE;
+    if ((ldq | ldk | ldv | ldo | lddq | lddk | lddv) & 3) return DSC_EALIGN;
+    if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(dout) || !dsc_aligned16(dq) ||
+        !dsc_aligned16(dk) || !dsc_aligned16(dv)) return DSC_EALIGN;
+    const size_t lds = sizeof(float) * ((size_t)(3 * nk + 2 * nq) * HP + 2 * 32 * HP + 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_attention_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(linear_attention_bwd_kernel, dim3(scenes * DSC_HEADS), dim3(128), lds,
+                       static_cast<hipStream_t>(stream), q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo,
+                       dq, (long)lddq, dk, (long)lddk, dv, (long)lddv, nq, nk, scale);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                     const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk, int64_t lddk,
+                                     float* dv, int64_t lddv, int32_t scenes, int32_t n, float scale, dsc_stream_t stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || scenes < 1 || n < 1) return DSC_EINVAL;
+    if (n > 160) return DSC_ERANGE;
+    if ((ldq | ldk | ldv | ldo | lddq | lddk | lddv) & 3) return DSC_EALIGN;
+    if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(dout) || !dsc_aligned16(dq) ||
+        !dsc_aligned16(dk) || !dsc_aligned16(dv)) return DSC_EALIGN;
+    const size_t lds = sizeof(float) * ((size_t)4 * n * HP + 3 * n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(scenes * DSC_HEADS), dim3(192), lds, static_cast<hipStream_t>(stream),
+                       q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo, dq, (long)lddq, dk, (long)lddk,
+                       dv, (long)lddv, n, scale);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx, int64_t count, int32_t act,
+                                      dsc_stream_t stream) {
+    if (!x || !dy || !dx || count < 1) return DSC_EINVAL;
+    long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy, dx,
+                       (long)count, act);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t cols,
+                                 dsc_stream_t stream) {
+    if (!in || !out || rows < 1 || cols < 1) return DSC_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, (long)ldi, out, (long)ldo, rows, cols);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}

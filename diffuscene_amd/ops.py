@@ -40,7 +40,7 @@ def as2d(w):
 
 
 def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
-                   gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE):
+                   gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None):
     """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
     pointers only; the caller keeps the tensors alive."""
     g = GemmArgs()
@@ -70,6 +70,8 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
     if scale_shift is not None:
         g.scale_shift, g.ld_ss = _mat(scale_shift, "scale_shift")
         g.ss_mode = ss_mode
+    if preact is not None:
+        g.preact, g.ld_preact = _mat(preact, "preact")
     return g
 
 
@@ -87,12 +89,13 @@ def gemm(a, w, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_N
 
 
 def gemm_gn_silu(a, w_std, bias, gamma, beta, tokens_per_scene, a2=None, scale_shift=None, ss_mode=SS_NONE,
-                 residual=None, eps=1e-5, out=None):
+                 residual=None, eps=1e-5, out=None, preact=None):
     w2 = as2d(w_std)
     if out is None:
         out = torch.empty((a.shape[0], w2.shape[0]), device=a.device, dtype=torch.float32)
     run_gemm(make_gemm_args(a, w_std, out, bias, a2, residual, gamma=gamma, beta=beta, eps=eps,
-                            tokens_per_scene=tokens_per_scene, scale_shift=scale_shift, ss_mode=ss_mode), gn=True)
+                            tokens_per_scene=tokens_per_scene, scale_shift=scale_shift, ss_mode=ss_mode,
+                            preact=preact), gn=True)
     return out
 
 
@@ -241,3 +244,137 @@ def complete_overwrite(x, partial, noise, t, sqrt_ac, sqrt_1mac):
                                                      sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(), b, n, p, c,
                                                      stream_ptr()), "dsc_complete_overwrite_f32")
     return x
+
+
+# ---------------------------------------------------------------------------------- training (backward) kernels
+
+_scratch = {}
+
+
+def scratch(device, floats):
+    """Per-device scratch for split reductions.  Kernels run in order on one stream, so one buffer is reused."""
+    t = _scratch.get(device)
+    if t is None or t.numel() < floats:
+        t = torch.empty(max(int(floats), 1 << 20), device=device, dtype=torch.float32)
+        _scratch[device] = t
+    return t
+
+
+def transpose(w, out=None, ldo=None):
+    wp, ldi = _mat(w, "w")
+    rows, cols = w.shape
+    if out is None:
+        out = torch.empty((cols, rows), device=w.device, dtype=torch.float32)
+    op, ld = _mat(out, "out")
+    _lib.check(_lib.fn("dsc_transpose_f32")(wp, ldi, op, ld, rows, cols, stream_ptr()), "dsc_transpose_f32")
+    return out
+
+
+def gemm_tn(a, dy, a2=None, kvalid=None, out=None):
+    """out[n][k] = sum_m dy[m][n] * [a|a2][m][k]"""
+    ap, lda = _mat(a, "a")
+    dp, ldd = _mat(dy, "dy")
+    k1 = a.shape[1]
+    a2p, lda2, k2 = (None, 0, 0)
+    if a2 is not None:
+        a2p, lda2 = _mat(a2, "a2")
+        k2 = a2.shape[1]
+    K = k1 + k2
+    kv = K if kvalid is None else kvalid
+    m, n = dy.shape
+    if out is None:
+        out = torch.empty((n, kv), device=a.device, dtype=torch.float32)
+    op, ldo = _mat(out, "out")
+    wsf = _lib.fn("dsc_gemm_tn_workspace_floats")(m, n, kv)
+    ws = scratch(a.device, wsf) if wsf else None
+    _lib.check(_lib.fn("dsc_gemm_tn_f32")(ap, lda, k1, a2p, lda2, k2, dp, ldd, op, ldo, m, n, kv,
+                                          ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                          stream_ptr()), "dsc_gemm_tn_f32")
+    return out
+
+
+def colsum(x, out=None):
+    xp, ldx = _mat(x, "x")
+    m, n = x.shape
+    if out is None:
+        out = torch.empty((n,), device=x.device, dtype=torch.float32)
+    ws = scratch(x.device, 64 * n)
+    _lib.check(_lib.fn("dsc_colsum_f32")(xp, ldx, m, n, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()),
+               "dsc_colsum_f32")
+    return out
+
+
+def gn_silu_bwd(z, dy, gamma, beta, ss, ss_mode, scenes, n_tok, eps=1e-5):
+    """-> dz [M,512], (dgamma, dbeta, dbias) [512] each, dss (per-scene [B,1024] | per-token [M,1024] | None)"""
+    zp, ldz = _mat(z, "z")
+    dp, ldy = _mat(dy, "dy")
+    M, Cc = z.shape
+    dz = torch.empty((M, Cc), device=z.device, dtype=torch.float32)
+    part = torch.empty((3, scenes, Cc), device=z.device, dtype=torch.float32)
+    dss = None
+    sp, ld_ss, ld_dss = None, 0, 0
+    if ss is not None and ss_mode != SS_NONE:
+        sp, ld_ss = _mat(ss, "ss")
+        dss = torch.empty((scenes if ss_mode == SS_PER_SCENE else M, 2 * Cc), device=z.device, dtype=torch.float32)
+        ld_dss = 2 * Cc
+    _lib.check(_lib.fn("dsc_gn_silu_bwd_f32")(zp, ldz, dp, ldy, _dev(gamma).data_ptr(), _dev(beta).data_ptr(), sp, ld_ss,
+                                              ss_mode if sp else SS_NONE, dz.data_ptr(), Cc, part[0].data_ptr(),
+                                              part[1].data_ptr(), part[2].data_ptr(),
+                                              dss.data_ptr() if dss is not None else None, ld_dss, scenes, n_tok, Cc,
+                                              eps, stream_ptr()), "dsc_gn_silu_bwd_f32")
+    # column-sums over the scenes for the three per-channel gradients
+    red = torch.empty((3, Cc), device=z.device, dtype=torch.float32)
+    for i in range(3):
+        colsum(part[i], out=red[i])
+    return dz, red[0], red[1], red[2], dss
+
+
+def weight_standardize_bwd(weights, dw_stds, eps=1e-5):
+    outs = [torch.empty_like(as2d(w)) for w in weights]
+    for i in range(0, len(weights), _lib.WS_MAX):
+        ws, gs, os_ = weights[i:i + _lib.WS_MAX], dw_stds[i:i + _lib.WS_MAX], outs[i:i + _lib.WS_MAX]
+        arr = (_lib.WsBwdItem * len(ws))()
+        for j, (w, g, o) in enumerate(zip(ws, gs, os_)):
+            w2, g2 = as2d(_dev(w)), _dev(g)
+            if not (w2.is_contiguous() and g2.is_contiguous()):
+                raise RuntimeError("weight_standardize_bwd needs contiguous matrices")
+            arr[j].w, arr[j].dw_std, arr[j].dw = w2.data_ptr(), g2.data_ptr(), o.data_ptr()
+            arr[j].rows, arr[j].cols = w2.shape
+        _lib.check(_lib.fn("dsc_weight_standardize_bwd_f32")(arr, len(ws), eps, stream_ptr()),
+                   "dsc_weight_standardize_bwd_f32")
+    return outs
+
+
+def layernorm_bwd(x, g, dy, eps=1e-5):
+    xp, ldx = _mat(x, "x")
+    dp, ldy = _mat(dy, "dy")
+    M, Dd = x.shape
+    dx = torch.empty((M, Dd), device=x.device, dtype=torch.float32)
+    nblk = min((M + 3) // 4, 512)
+    part = torch.empty((nblk, Dd), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.fn("dsc_layernorm_bwd_f32")(xp, ldx, _dev(g).data_ptr(), dp, ldy, dx.data_ptr(), Dd, part.data_ptr(),
+                                                nblk, M, Dd, eps, stream_ptr()), "dsc_layernorm_bwd_f32")
+    return dx, colsum(part)
+
+
+def linear_attention_bwd(q, k, v, dout, dq, dk, dv, scenes, nq, nk, scale):
+    args = []
+    for t, nme in ((q, "q"), (k, "k"), (v, "v"), (dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        args += list(_mat(t, nme))
+    _lib.check(_lib.fn("dsc_linear_attention_bwd_f32")(*args, scenes, nq, nk, scale, stream_ptr()),
+               "dsc_linear_attention_bwd_f32")
+
+
+def attention_bwd(q, k, v, dout, dq, dk, dv, scenes, n, scale):
+    args = []
+    for t, nme in ((q, "q"), (k, "k"), (v, "v"), (dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        args += list(_mat(t, nme))
+    _lib.check(_lib.fn("dsc_attention_bwd_f32")(*args, scenes, n, scale, stream_ptr()), "dsc_attention_bwd_f32")
+
+
+def activation_bwd(x, dy, act):
+    _c(x, "x"); _c(dy, "dy")
+    dx = torch.empty_like(x)
+    _lib.check(_lib.fn("dsc_activation_bwd_f32")(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), act,
+                                                 stream_ptr()), "dsc_activation_bwd_f32")
+    return dx

@@ -68,6 +68,7 @@ typedef struct dsc_gemm_args {
     const float* gamma; const float* beta; float eps;
     int32_t tokens_per_scene;                    /* N: GroupNorm reduces over 64 channels x N tokens (:164) */
     const float* scale_shift; int64_t ld_ss; int32_t ss_mode; /* row layout [scale(n) | shift(n)] */
+    float* preact; int64_t ld_preact;            /* optional: pre-norm conv output z = [A1|A2].W^T + bias, saved for backward */
 } dsc_gemm_args;
 
 int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
@@ -154,6 +155,59 @@ int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t st
 int dsc_complete_overwrite_f32(float* x, const float* partial, const float* noise, const int64_t* t,
                                const float* sqrt_ac, const float* sqrt_1mac,
                                int32_t b, int32_t n, int32_t p, int32_t c, dsc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training: hand-written backward of the denoiser (the reference relies on torch autograd through
+ * denoise_net.py; train_on_batch, diffusion_scene_layout_ddpm.py:456-473).  Input gradients
+ * dA = dY . W reuse dsc_gemm_f32 on transposed weights (dsc_transpose_f32).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Weight gradient  out[n][k] = sum_m dy[m][n] * [a1|a2][m][k]  (fp32 MFMA, split over tokens, deterministic
+ * two-stage reduction through `workspace`, sized by dsc_gemm_tn_workspace_floats).  Columns >= kvalid of a
+ * zero-padded small-K input are not stored; out is dense [n][kvalid] (ldo == kvalid) when split. */
+int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const float* a2, int64_t lda2, int32_t k2,
+                    const float* dy, int64_t ldd, float* out, int64_t ldo, int32_t m, int32_t n, int32_t kvalid,
+                    float* workspace, int64_t workspace_floats, dsc_stream_t stream);
+int64_t dsc_gemm_tn_workspace_floats(int32_t m, int32_t n, int32_t k);
+
+/* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */
+int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,
+                   int64_t workspace_floats, dsc_stream_t stream);
+
+/* Backward of the GroupNorm + (scale+1, shift) + SiLU epilogue of dsc_gemm_gn_silu_f32 (Block.forward,
+ * denoise_net.py:167-176) from the saved pre-norm output z.  dz feeds the GEMM backward; dgamma_p / dbeta_p /
+ * dbias_p are per-scene partials [scenes][512] (reduce with dsc_colsum_f32); dss is [scenes][1024] for
+ * DSC_SS_PER_SCENE, [m][1024] for PER_TOKEN / PER_SLOT (caller reduces over the batch for PER_SLOT). */
+int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy, int64_t ldy, const float* gamma,
+                        const float* beta, const float* scale_shift, int64_t ld_ss, int32_t ss_mode,
+                        float* dz, int64_t lddz, float* dgamma_p, float* dbeta_p, float* dbias_p,
+                        float* dss, int64_t ld_dss, int32_t scenes, int32_t tokens_per_scene, int32_t channels,
+                        float eps, dsc_stream_t stream);
+
+/* Backward of dsc_weight_standardize_f32: dw = rstd * (dw_std - mean(dw_std) - w_std * mean(dw_std * w_std)). */
+typedef struct dsc_ws_bwd_item { const float* w; const float* dw_std; float* dw; int32_t rows; int32_t cols; } dsc_ws_bwd_item;
+int dsc_weight_standardize_bwd_f32(const dsc_ws_bwd_item* items, int32_t count, float eps, dsc_stream_t stream);
+
+/* Backward of dsc_layernorm_f32: dx, and per-block partials of the gain gradient [partial_rows][512]. */
+int dsc_layernorm_bwd_f32(const float* x, int64_t ldx, const float* g, const float* dy, int64_t ldy, float* dx,
+                          int64_t lddx, float* dg_partial, int32_t partial_rows, int32_t m, int32_t d, float eps,
+                          dsc_stream_t stream);
+
+int dsc_linear_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                 const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk, int64_t lddk,
+                                 float* dv, int64_t lddv, int32_t scenes, int32_t nq, int32_t nk, float scale,
+                                 dsc_stream_t stream);
+
+int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                          const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk, int64_t lddk,
+                          float* dv, int64_t lddv, int32_t scenes, int32_t n, float scale, dsc_stream_t stream);
+
+/* dx = dy * act'(x) */
+int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx, int64_t count, int32_t act, dsc_stream_t stream);
+
+/* out[c][r] = in[r][c] */
+int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t cols,
+                      dsc_stream_t stream);
 
 #ifdef __cplusplus
 }

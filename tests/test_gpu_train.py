@@ -1,0 +1,241 @@
+"""GPU: hand-written backward kernels vs torch autograd of the same op (fp64 on CPU), and the full training-loss
+gradient of the HIP denoiser vs the REAL reference's gradients (tests/golden/p_losses.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_torch as R  # noqa: E402
+from oracle import weights as W  # noqa: E402
+from oracle.make_golden import CASES, case_inputs  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 77 * len(shape) + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def G(t):
+    return t.to(dev()).requires_grad_(True)
+
+
+@pytest.mark.parametrize("m,n,k,k2", [(300, 512, 512, 0), (1000, 512, 512, 512), (64, 2048, 512, 0), (333, 25, 512, 0),
+                                      (20480, 512, 512, 0)])
+def test_linear_fn_backward(m, n, k, k2):
+    from diffuscene_amd.autograd_ops import LinearFn
+    a, w, b, r = rnd(m, k, seed=1), rnd(n, k + k2, seed=2, scale=0.1), rnd(n, seed=3), rnd(m, n, seed=4)
+    a2 = rnd(m, k2, seed=5) if k2 else None
+    dy = rnd(m, n, seed=6)
+    ga, gw, gb, gr = G(a), G(w), G(b), G(r)
+    ga2 = G(a2) if k2 else None
+    y = LinearFn.apply(ga, gw, gb, ga2, gr)
+    y.backward(dy.to(dev()))
+    A = torch.cat([a, a2], 1).double() if k2 else a.double()
+    A.requires_grad_(True)
+    wd, bd, rd = w.double().requires_grad_(True), b.double().requires_grad_(True), r.double().requires_grad_(True)
+    (A @ wd.T + bd + rd).backward(dy.double())
+    tol = 3e-5 if m > 5000 else 5e-6
+    assert rel(ga.grad, A.grad[:, :k]) < tol
+    if k2:
+        assert rel(ga2.grad, A.grad[:, k:]) < tol
+    assert rel(gw.grad, wd.grad) < tol and rel(gb.grad, bd.grad) < tol and rel(gr.grad, rd.grad) < 1e-7
+
+
+def test_smallk_and_act_backward():
+    from diffuscene_amd.autograd_ops import ActFn, SmallKLinearFn
+    from diffuscene_amd._lib import ACT_GELU, ACT_SILU
+    M = 500
+    x = rnd(M, 65, seed=7)
+    for c0, k in ((0, 8), (8, 25), (33, 32), (0, 5)):
+        w, b, dy = rnd(512, k, 1, seed=8 + k), rnd(512, seed=9 + k), rnd(M, 512, seed=10 + k)
+        gw, gb = G(w), G(b)
+        y = ActFn.apply(SmallKLinearFn.apply(x.to(dev())[:, c0:c0 + k], gw, gb), ACT_GELU)
+        y.backward(dy.to(dev()))
+        wd, bd = w.double()[:, :, 0].requires_grad_(True), b.double().requires_grad_(True)
+        F.gelu(x[:, c0:c0 + k].double() @ wd.T + bd).backward(dy.double())
+        assert rel(gw.grad[:, :, 0], wd.grad) < 5e-6 and rel(gb.grad, bd.grad) < 5e-6
+    xs = rnd(1000, 64, seed=11) * 3
+    gx = G(xs)
+    ActFn.apply(gx, ACT_SILU).backward(torch.ones(1000, 64, device=dev()))
+    xd = xs.double().requires_grad_(True)
+    F.silu(xd).sum().backward()
+    assert rel(gx.grad, xd.grad) < 2e-6
+
+
+@pytest.mark.parametrize("B,N,mode,two", [(3, 80, 2, False), (5, 21, 1, False), (4, 12, 3, True), (2, 33, 0, False)])
+def test_conv_gn_silu_backward(B, N, mode, two):
+    from diffuscene_amd.autograd_ops import ConvGnSiluFn
+    M, D = B * N, 512
+    K = 1024 if two else 512
+    a, w, b = rnd(M, 512, seed=12), rnd(D, K, seed=13, scale=0.08), rnd(D, seed=14)
+    a2 = rnd(M, 512, seed=15) if two else None
+    gamma, beta, res, dy = 1 + 0.1 * rnd(D, seed=16), 0.1 * rnd(D, seed=17), rnd(M, D, seed=18), rnd(M, D, seed=19)
+    rows = {0: 0, 1: M, 2: B, 3: N}[mode]
+    ss = rnd(rows, 2 * D, seed=20) if rows else None
+    ga, gw, gb, gg, gbe, gres = G(a), G(w), G(b), G(gamma), G(beta), G(res)
+    ga2 = G(a2) if two else None
+    gss = G(ss) if ss is not None else None
+    y = ConvGnSiluFn.apply(ga, gw, gb, gg, gbe, ga2, gss, gres, N, mode)
+    y.backward(dy.to(dev()))
+    A = (torch.cat([a, a2], 1) if two else a).double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gd, bed, rd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), res.double().requires_grad_(True)
+    ssd = ss.double().requires_grad_(True) if ss is not None else None
+    z = (A @ wd.T + bd).reshape(B, N, D).permute(0, 2, 1)
+    g = F.group_norm(z, 8, gd, bed, eps=1e-5)
+    if mode:
+        e = {1: lambda: ssd.reshape(B, N, 2 * D), 2: lambda: ssd[:, None, :].expand(B, N, 2 * D),
+             3: lambda: ssd[None].expand(B, N, 2 * D)}[mode]().permute(0, 2, 1)
+        g = g * (e[:, :D] + 1) + e[:, D:]
+    ref = F.silu(g).permute(0, 2, 1).reshape(M, D) + rd
+    ref.backward(dy.double())
+    assert rel(y, ref) < 5e-6
+    assert rel(ga.grad, A.grad[:, :512]) < 2e-5
+    if two:
+        assert rel(ga2.grad, A.grad[:, 512:]) < 2e-5
+    for name, mine, theirs in (("w", gw.grad, wd.grad), ("bias", gb.grad, bd.grad), ("gamma", gg.grad, gd.grad),
+                               ("beta", gbe.grad, bed.grad), ("res", gres.grad, rd.grad)):
+        assert rel(mine, theirs) < 2e-5, (name, rel(mine, theirs))
+    if ss is not None:
+        assert rel(gss.grad, ssd.grad) < 2e-5
+
+
+def test_weight_standardize_backward():
+    from diffuscene_amd.autograd_ops import WeightStandardizeAllFn
+    ws = [rnd(512, 512, 1, seed=21), rnd(512, 1024, 1, seed=22) + 0.2]
+    dys = [rnd(512, 512, seed=23), rnd(512, 1024, seed=24)]
+    gs = [G(w) for w in ws]
+    outs = WeightStandardizeAllFn.apply(*gs)
+    (outs[0] * dys[0].to(dev())).sum().add((outs[1] * dys[1].to(dev())).sum()).backward()
+    for w, dy, g in zip(ws, dys, gs):
+        wd = w.double().requires_grad_(True)
+        mean = wd.mean(dim=(1, 2), keepdim=True)
+        var = wd.var(dim=(1, 2), unbiased=False, keepdim=True)
+        (((wd - mean) * (var + 1e-5).rsqrt())[:, :, 0] * dy.double()).sum().backward()
+        assert rel(g.grad, wd.grad) < 1e-5
+
+
+def test_layernorm_backward():
+    from diffuscene_amd.autograd_ops import LayerNormFn
+    x, g, r, dy = rnd(777, 512, seed=25) * 2 + 0.3, 1 + 0.1 * rnd(512, seed=26), rnd(777, 512, seed=27), rnd(777, 512, seed=28)
+    gx, gg, gr = G(x), G(g), G(r)
+    LayerNormFn.apply(gx, gg, gr).backward(dy.to(dev()))
+    xd, gd, rd = x.double().requires_grad_(True), g.double().requires_grad_(True), r.double().requires_grad_(True)
+    ((xd - xd.mean(1, keepdim=True)) * (xd.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * gd + rd).backward(dy.double())
+    assert rel(gx.grad, xd.grad) < 5e-6 and rel(gg.grad, gd.grad) < 5e-6 and rel(gr.grad, rd.grad) < 1e-7
+
+
+@pytest.mark.parametrize("B,N", [(3, 80), (2, 12), (1, 160)])
+def test_attention_cores_backward(B, N):
+    from diffuscene_amd.autograd_ops import AttentionFn, LinearAttentionCrossFn, LinearAttentionSelfFn
+    qkv, dy = rnd(B * N, 384, seed=29) * 2, rnd(B * N, 128, seed=30)
+    sc = 32 ** -0.5
+
+    def heads(t, n):
+        return t.reshape(B, n, 4, 32).permute(0, 2, 3, 1)
+
+    g = G(qkv)
+    LinearAttentionSelfFn.apply(g, B, N, sc).backward(dy.to(dev()))
+    qd = qkv.double().requires_grad_(True)
+    ref = R._linear_attention_core(heads(qd[:, :128], N), heads(qd[:, 128:256], N), heads(qd[:, 256:], N))
+    ref.permute(0, 2, 1).reshape(B * N, 128).backward(dy.double())
+    assert rel(g.grad, qd.grad) < 1e-5, ("linear", rel(g.grad, qd.grad))
+
+    g = G(qkv)
+    AttentionFn.apply(g, B, N, sc).backward(dy.to(dev()))
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = heads(qd[:, :128], N) * sc, heads(qd[:, 128:256], N), heads(qd[:, 256:], N)
+    attn = torch.einsum("bhdi,bhdj->bhij", q, k).softmax(-1)
+    torch.einsum("bhij,bhdj->bhid", attn, v).permute(0, 2, 1, 3).reshape(B * N, 128).backward(dy.double())
+    assert rel(g.grad, qd.grad) < 1e-5, ("softmax", rel(g.grad, qd.grad))
+
+    L = 7
+    q0, kv = rnd(B * N, 128, seed=31) * 2, rnd(B * L, 256, seed=32) * 2
+    gq, gkv = G(q0), G(kv)
+    LinearAttentionCrossFn.apply(gq, gkv, B, N, L, sc).backward(dy.to(dev()))
+    qd, kvd = q0.double().requires_grad_(True), kv.double().requires_grad_(True)
+    ref = R._linear_attention_core(heads(qd, N), heads(kvd[:, :128], L), heads(kvd[:, 128:], L))
+    ref.permute(0, 2, 1).reshape(B * N, 128).backward(dy.double())
+    assert rel(gq.grad, qd.grad) < 1e-5 and rel(gkv.grad, kvd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["uncond_bedroom", "uncond_living"])
+def test_training_gradients_match_reference(golden_dir, tmp_path, name):
+    """p_losses (+IoU term) and the gradient of EVERY parameter vs the real reference (golden): per-parameter gradient
+    norms within 2e-4 relative (of the largest norm for tiny ones), committed slices within 1e-4."""
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    g = np.load(os.path.join(golden_dir, "p_losses.npz"))
+    names = json.load(open(os.path.join(golden_dir, "grad_names_%s.json" % name)))
+    kw, x, t, cond, cross = case_inputs(name)
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    net = Unet1D(**kw)
+    net.load_state_dict(W.synth_state_dict(kw))
+    net.to(dev())
+    cfg = dict(objectness_dim=0, class_dim=kw["class_dim"], angle_dim=2, objfeat_dim=32)
+    diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=True,
+                          train_stats_file=str(stats))
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    losses, scal = diff.diffusion.p_losses(diff._denoise, x.to(dev()), t.to(dev()), noise=noise.to(dev()),
+                                           condition=cond.to(dev()), condition_cross=None)
+    losses.mean().backward()
+    assert rel(losses, g[name + ".losses"]) < 1e-4
+    for k, v in scal.items():
+        assert abs(float(v) - float(g[name + "." + k])) <= 1e-4 * max(1.0, abs(float(g[name + "." + k]))), k
+    params = dict(net.named_parameters())
+    gn = np.array([float(params[k].grad.norm()) for k in names])
+    ref = g[name + ".grad_norms"]
+    err = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+    worst = int(err.argmax())
+    print("worst grad-norm rel err %.3g at %s" % (err[worst], names[worst]))
+    assert err.max() < 2e-4
+    assert rel(net.init_conv.bias.grad, g[name + ".grad.init_conv.bias"]) < 1e-4
+    assert rel(net.mid_attn.fn.fn.to_qkv.weight.grad[:8, :16, 0], g[name + ".grad.mid_attn.to_qkv"]) < 1e-4
+    assert rel(net.downs[0][0].block1.proj.weight.grad[:8, :16, 0], g[name + ".grad.downs0.block1.proj"]) < 1e-4
+
+
+def test_train_on_batch_runs_and_learns(tmp_path):
+    """train_on_batch end to end (Adam, clip, logging): the loss on a fixed batch must go down."""
+    from diffuscene_amd.networks import optimizer_factory
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM, train_on_batch
+    from diffuscene_amd.stats_logger import StatsLogger
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 62, "latent_dim": 0,
+           "room_mask_condition": False, "sample_num_points": 12, "objectness_dim": 0, "objfeat_dim": 32,
+           "class_dim": 22, "angle_dim": 2, "learnable_embedding": True, "instance_condition": True,
+           "instance_emb_dim": 128,
+           "diffusion_kwargs": dict(schedule_type="linear", beta_start=1e-4, beta_end=0.02, time_num=1000,
+                                    loss_type="mse", model_mean_type="v", model_var_type="fixedsmall",
+                                    loss_separate=True, loss_iou=True, train_stats_file=str(stats)),
+           "net_kwargs": dict(W.UNCOND_BEDROOM)}
+    torch.manual_seed(0)
+    m = DiffusionSceneLayout_DDPM(23, None, cfg).to(dev())
+    opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4}, m.parameters())
+    x = W.synth_scene_batch(8, 12, 22, 32, seed=1).to(dev())
+    sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
+              "angles": x[:, :, 6:8].contiguous(), "class_labels": x[:, :, 8:30].contiguous(),
+              "objfeats_32": x[:, :, 30:62].contiguous(), "room_layout": torch.zeros(8, 1, 64, 64, device=dev())}
+    ls = []
+    for i in range(12):
+        torch.manual_seed(123)                       # same t / noise every step: a fixed objective
+        ls.append(train_on_batch(m, opt, sample, {"training": {"max_grad_norm": 10}}))
+    print("losses", ["%.4f" % v for v in ls])
+    assert all(np.isfinite(ls)) and ls[-1] < 0.8 * ls[0]
+    assert StatsLogger.instance()["gradnorm"].value > 0
+    assert m.positional_embedding.grad is not None and float(m.positional_embedding.grad.abs().sum()) > 0

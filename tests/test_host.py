@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from diffuscene_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "diffuscene_hip.h")).read()
-    declared = set(re.findall(r"^\s*int\s+(dsc_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(dsc_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     lib = _lib.load()
     for name in declared:
