@@ -54,7 +54,15 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[3]):
             wt = torch.zeros((K, npad), device=w.device) if npad != n else torch.empty((K, n), device=w.device)
             ops.transpose(w2, out=wt[:, :n] if npad != n else wt)
-            d_in = ops.gemm(dyp, wt)                # [M, K] = dy @ w
+            if npad > 4096:
+                # long reductions (the packed 19x1024 time-MLP outputs): accumulate in chunks of 2048 so the fp32
+                # error stays that of a blocked sum instead of one 19456-term sequential chain
+                d_in = None
+                for c0 in range(0, npad, 2048):
+                    c1 = min(c0 + 2048, npad)
+                    d_in = ops.gemm(dyp[:, c0:c1], wt[:, c0:c1], residual=d_in)
+            else:
+                d_in = ops.gemm(dyp, wt)            # [M, K] = dy @ w
             da = d_in[:, :k1] if a2 is not None else d_in
             da2 = d_in[:, k1:] if a2 is not None else None
         if ctx.needs_input_grad[1]:
