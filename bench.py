@@ -1,13 +1,16 @@
 #!/usr/bin/env python
 """Benchmark of the DiffuScene DDPM hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
 
-    python bench.py --gpus N --steps K --warmup W [--mode sample|train] [--batch 256] [--objects 80]
+    python bench.py --gpus N --steps K --warmup W [--mode both|sample|train] [--batch 256] [--objects 80]
 
 Workload (BASELINE.json `metric`): uncond living/dining rooms scaled to N=80 objects, B=256 scenes per GPU,
 C=65 channels, fp32, synthetic scenes with the real encoders' value distribution, random-init weights.
   mode=sample : a step = one reverse-diffusion denoiser step (Unet1D forward + fused posterior step) of a
                 1000-step p_sample_loop, replayed from the captured hipGraph.
   mode=train  : a step = train_on_batch semantics (q_sample, forward, loss incl. IoU, backward, clip(10), Adam).
+  mode=both   : (default, BASELINE.json metric "train + 1000-step sample") the K timed denoiser steps are ceil(K/2)
+                sampling steps followed by floor(K/2) training steps inside ONE timed region; the two rates are also
+                reported separately ("sample", "train").
 N > 1: one process per GPU (torchrun), batch sharded by rank (weak scaling: per-GPU batch fixed); sampling
 needs no collective, training all-reduces the gradients over RCCL.
 Prints ONE JSON line on rank 0.
@@ -68,47 +71,55 @@ def barrier(ws):
     torch.cuda.synchronize()
 
 
-def bench_sample(args, model, device, ws):
-    from diffuscene_amd.sampler import _StepGraph
-    B, N, C = args.batch, args.objects, 65
-    diff = model.diffusion.diffusion
-    cond = model._instance_condition(B, device)
-    with torch.no_grad():
-        g = _StepGraph(diff, model.diffusion.model, (B, N, C), device, cond, None, True)
+class SampleRunner:
+    """Reverse-diffusion steps replayed from the captured hipGraph (sampler._StepGraph)."""
+
+    def __init__(self, args, model, device):
+        from diffuscene_amd.sampler import _StepGraph
+        B, N, C = args.batch, args.objects, 65
+        cond = model._instance_condition(B, device)
+        with torch.no_grad():
+            self.g = _StepGraph(model.diffusion.diffusion, model.diffusion.model, (B, N, C), device, cond, None, True)
         log("graph captured")
-        g.x.normal_()
-        g.t.fill_(999)
-        for _ in range(args.warmup):
-            g.graph.replay()
-        g.t.fill_(999)
-        barrier(ws)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            g.graph.replay()
-        barrier(ws)
-        dt = time.perf_counter() - t0
-        assert torch.isfinite(g.x).all()
-    return dt, g
+        self.g.x.normal_()
+        self.g.t.fill_(999)
+
+    def run(self, n):
+        for _ in range(n):
+            self.g.graph.replay()
+
+    def reset(self):
+        self.g.t.fill_(999)
 
 
-def bench_train(args, model, cfg, device, ws):
-    from diffuscene_amd.networks import optimizer_factory
-    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import train_on_batch
-    from oracle import weights as W
-    B, N = args.batch, args.objects
-    rank = dist.get_rank() if ws > 1 else 0
-    x = W.synth_scene_batch(B, N, 25, 32, seed=100 + rank).to(device)
-    sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
-              "angles": x[:, :, 6:8].contiguous(), "class_labels": x[:, :, 8:33].contiguous(),
-              "objfeats_32": x[:, :, 33:65].contiguous(), "room_layout": torch.zeros(B, 1, 64, 64, device=device)}
-    opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4}, filter(lambda p: p.requires_grad, model.parameters()))
-    tcfg = {"training": {"max_grad_norm": 10}}
-    for _ in range(args.warmup):
-        train_on_batch(model, opt, sample, tcfg)
+class TrainRunner:
+    """train_on_batch on a fixed synthetic batch (per-rank shard of the global batch)."""
+
+    def __init__(self, args, model, device, ws):
+        from diffuscene_amd.networks import optimizer_factory
+        from oracle import weights as W
+        B, N = args.batch, args.objects
+        rank = dist.get_rank() if ws > 1 else 0
+        x = W.synth_scene_batch(B, N, 25, 32, seed=100 + rank).to(device)
+        self.sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
+                       "angles": x[:, :, 6:8].contiguous(), "class_labels": x[:, :, 8:33].contiguous(),
+                       "objfeats_32": x[:, :, 33:65].contiguous(),
+                       "room_layout": torch.zeros(B, 1, 64, 64, device=device)}
+        self.model = model
+        self.opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4},
+                                     filter(lambda p: p.requires_grad, model.parameters()))
+        self.tcfg = {"training": {"max_grad_norm": 10}}
+
+    def run(self, n):
+        from diffuscene_amd.networks.diffusion_scene_layout_ddpm import train_on_batch
+        for _ in range(n):
+            train_on_batch(self.model, self.opt, self.sample, self.tcfg)
+
+
+def timed(ws, fn):
     barrier(ws)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        train_on_batch(model, opt, sample, tcfg)
+    fn()
     barrier(ws)
     return time.perf_counter() - t0
 
@@ -169,7 +180,12 @@ def cpu_baseline(args, mode):
         for p in params:
             p.grad = None
 
-    fn = one_sample_step if mode == "sample" else one_train_step
+    if mode == "both":
+        def fn():
+            one_sample_step()
+            one_train_step()
+    else:
+        fn = one_sample_step if mode == "sample" else one_train_step
     # pick the host thread count that runs the oracle fastest on this box (all logical CPUs is rarely it)
     ncpu = os.cpu_count() or 1
     best = None
@@ -193,11 +209,11 @@ def cpu_baseline(args, mode):
         el = time.perf_counter() - t0
         if el > 12.0 or n >= 30:
             break
-    per_full = (el / n) * (args.batch / Bs)
+    per_full = (el / n) * (args.batch / Bs) / (2.0 if mode == "both" else 1.0)
     return {"value": round(1.0 / per_full, 4), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": "%d %s steps of the oracle on %d of %d scenes (N=%d), scaled x%d to the full batch%s"
-                      % (n, mode, Bs, args.batch, N, args.batch // Bs,
-                         "" if mode == "sample" else " (fwd+bwd only, no optimizer)")}
+                      % (n, "sample+train pairs" if mode == "both" else mode, Bs, args.batch, N, args.batch // Bs,
+                         "" if mode == "sample" else " (train = fwd+bwd only, no optimizer)")}
 
 
 def main():
@@ -205,7 +221,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", default=os.environ.get("DSC_BENCH_MODE", "sample"), choices=["sample", "train"])
+    ap.add_argument("--mode", default=os.environ.get("DSC_BENCH_MODE", "both"), choices=["both", "sample", "train"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--objects", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,23 +241,43 @@ def main():
     model, cfg = build_model(args, device)
     log("model on device")
     plan = None
-    if args.mode == "sample":
-        dt, g = bench_sample(args, model, device, ws)
-        plan = g.plan
-    else:
-        dt = bench_train(args, model, cfg, device, ws)
-    log("timed region done: %.3f s for %d steps" % (dt, args.steps))
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    n_s = {"both": (args.steps + 1) // 2, "sample": args.steps, "train": 0}[args.mode]
+    n_t = args.steps - n_s
+    sr = SampleRunner(args, model, device) if n_s else None
+    tr = TrainRunner(args, model, device, ws) if n_t else None
+    if sr:
+        sr.run(args.warmup)
+        sr.reset()
+        plan = sr.g.plan
+    if tr:
+        tr.run(args.warmup)
+
+    def region():
+        if sr:
+            sr.run(n_s)
+        if tr:
+            tr.run(n_t)
+
+    dt = timed(ws, region)
+    log("timed region done: %.3f s for %d steps (%d sample + %d train)" % (dt, args.steps, n_s, n_t))
+    parts = {}
+    if args.mode == "both":          # the two rates separately (outside the headline region)
+        sr.reset()
+        parts["sample"] = timed(ws, lambda: sr.run(n_s)) / n_s
+        parts["train"] = timed(ws, lambda: tr.run(n_t)) / max(n_t, 1)
+    tmax = torch.tensor([dt] + [parts.get(k, 0.0) for k in ("sample", "train")], device=device, dtype=torch.float64)
     if ws > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = float(tmax[0].item())
+    if parts:
+        parts = {"sample": float(tmax[1].item()), "train": float(tmax[2].item())}
 
     if rank == 0:
         B, N = args.batch, args.objects
         steps_per_s = args.steps * ws / dt        # whole job: every rank advances its own B scenes one step
         out = {
             "metric": "denoiser steps/sec (%s) at B=256, N=80 objects" % (
-                "1000-step sample loop" if args.mode == "sample" else "train step"),
+                {"sample": "1000-step sample loop", "train": "train step", "both": "train + 1000-step sample"}[args.mode]),
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": ws, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -250,8 +286,10 @@ def main():
                        "global_batch": B * ws, "parallelism": "dp%d" % ws if ws > 1 else "single"},
         }
         F = unet_forward_flops(B, N)
-        mult = 1.0 if args.mode == "sample" else 3.0
-        out["model_tflops"] = round(mult * F * args.steps / dt / 1e12, 2)        # per GPU, algorithmic
+        out["model_tflops"] = round(F * (n_s + 3.0 * n_t) / dt / 1e12, 2)        # per GPU, algorithmic (train = 3F)
+        for k, v in parts.items():
+            out[k] = {"steps_per_s": round(ws / v, 3), "ms_per_step": round(v * 1e3, 3),
+                      "tflops_per_gpu": round((1.0 if k == "sample" else 3.0) * F / v / 1e12, 2)}
         out["model_frac_of_fp32_mfma_peak"] = round(out["model_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
         if plan is None:
             with torch.no_grad():

@@ -1,0 +1,67 @@
+// Tuning harness (NOT part of the product library): instantiates variants of the product GEMM kernel template
+// (diffuscene_amd/csrc/gemm_core.h) so tools/gemm_tune.py can time them on a real MI355X.
+#define DSC_GEMM_TIMING 1
+#include "../diffuscene_amd/csrc/gemm_core.h"
+
+__device__ long long g_dsc_timing[4096 * 8];
+
+extern "C" int tune_read_timing(long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dsc_timing), sizeof(long long) * 8 * nblocks);
+}
+
+using dsc_gemm::gemm_kernel;
+
+template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false>
+static int run(const dsc_gemm_args* a, hipStream_t s, int stagger) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
+    const int nrb = (a->m + rpb - 1) / rpb, ncb = (a->n + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
+    return (int)hipGetLastError();
+}
+
+#define VP(id, TM, TN, WM, WN, BK, MINW) \
+    case id: return gn ? run<TM, TN, WM, WN, true, BK, true, MINW, true, true>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, true, MINW, true, true>(a, s, stagger);
+
+#define V(id, TM, TN, WM, WN, BK, DB, MINW, XCD) \
+    case id: return gn ? run<TM, TN, WM, WN, true, BK, DB, MINW, XCD>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, DB, MINW, XCD>(a, s, stagger);
+
+extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* stream, int stagger);
+extern "C" int tune_launch(int variant, int gn, const dsc_gemm_args* a, void* stream) { return tune_launch2(variant, gn, a, stream, 0); }
+extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* stream, int stagger) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (variant) {
+        V(0, 5, 1, 1, 4, 32, false, 2, false)
+        V(1, 5, 1, 1, 4, 32, false, 2, true)
+        V(2, 5, 1, 1, 4, 16, true, 2, false)
+        V(3, 5, 1, 1, 4, 16, true, 2, true)
+        V(4, 5, 1, 1, 8, 32, true, 2, false)
+        V(5, 5, 1, 1, 8, 32, true, 2, true)
+        V(6, 5, 1, 1, 8, 32, false, 2, true)
+        V(7, 5, 1, 1, 8, 64, false, 2, true)
+        V(8, 5, 2, 1, 4, 32, true, 1, true)
+        V(9, 5, 1, 1, 4, 64, false, 2, true)
+        V(10, 5, 1, 1, 4, 32, true, 1, true)
+        V(11, 5, 1, 1, 8, 16, true, 2, true)
+        V(12, 5, 2, 1, 4, 16, true, 1, true)
+        VP(13, 5, 1, 1, 4, 16, 2)
+        VP(14, 5, 1, 1, 8, 32, 2)
+        VP(15, 5, 1, 1, 8, 16, 2)
+        VP(16, 5, 1, 1, 4, 32, 1)
+        VP(17, 5, 2, 1, 4, 16, 1)
+    }
+    return -1;
+}
+
+extern "C" const char* tune_name(int variant) {
+    static const char* names[] = {
+        "0: 160x128 4w BK32 single 2blk/CU (round-1 baseline)", "1: baseline + XCD remap",
+        "2: 160x128 4w BK16 double-buffered", "3: 160x128 4w BK16 DB + XCD",
+        "4: 160x256 8w BK32 DB", "5: 160x256 8w BK32 DB + XCD", "6: 160x256 8w BK32 single + XCD",
+        "7: 160x256 8w BK64 single + XCD", "8: 160x256 4w(5x2 tiles) BK32 DB 1 wave/SIMD + XCD",
+        "9: 160x128 4w BK64 single + XCD", "10: 160x128 4w BK32 DB (1 blk/CU) + XCD",
+        "11: 160x256 8w BK16 DB + XCD", "12: 160x256 4w(5x2) BK16 DB + XCD",
+        "13: PIPE 160x128 4w BK16 (2 blk/CU)", "14: PIPE 160x256 8w BK32 (1 blk/CU)", "15: PIPE 160x256 8w BK16",
+        "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD"};
+    return (variant >= 0 && variant < 18) ? names[variant] : nullptr;
+}
