@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffuscene_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
-SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT = 0, 1, 2, 3
+SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
 MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
 WS_MAX = 64
 MAX_TOKENS_PER_SCENE = 160
@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("tokens_per_scene", C.c_int32),
         ("scale_shift", C.c_void_p), ("ld_ss", C.c_int64), ("ss_mode", C.c_int32),
         ("preact", C.c_void_p), ("ld_preact", C.c_int64),
+        ("ss_index", C.c_void_p),
     ]
 
 
@@ -72,12 +73,12 @@ SIGNATURES = {
                                    c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "dsc_add_scalar_i64": (C.c_int, [c_i64p, C.c_int32, C.c_int64, C.c_void_p]),
     "dsc_gemm_tn_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p,
-                                  C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
+                                  C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_gemm_tn_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
-                                      c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_float, C.c_void_p]),
+                                      c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "dsc_weight_standardize_bwd_f32": (C.c_int, [C.POINTER(WsBwdItem), C.c_int32, C.c_float, C.c_void_p]),
     "dsc_layernorm_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),

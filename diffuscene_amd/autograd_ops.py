@@ -66,9 +66,13 @@ class LinearFn(Function):
             da = d_in[:, :k1] if a2 is not None else d_in
             da2 = d_in[:, k1:] if a2 is not None else None
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(a, dyp, a2=a2)         # [n_pad, K]
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dw, db = ops.gemm_tn(a, dyp, a2=a2, want_bias=True)      # bias gradient rides on the same pass over dy
+                db = db[:n]
+            else:
+                dw = ops.gemm_tn(a, dyp, a2=a2)     # [n_pad, K]
             dw = dw[:n].reshape(w.shape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dyp)[:n]
         return da, dw, db, da2, (dy if ctx.has_res else None)
 
@@ -89,8 +93,8 @@ class SmallKLinearFn(Function):
     def backward(ctx, dy):
         xpad, = ctx.saved_tensors
         dyd = _dense(dy)
-        dw = ops.gemm_tn(xpad, dyd, kvalid=ctx.k).reshape(ctx.wshape)
-        return None, dw, ops.colsum(dyd)
+        dw, db = ops.gemm_tn(xpad, dyd, kvalid=ctx.k, want_bias=True)
+        return None, dw.reshape(ctx.wshape), db
 
 
 class ActFn(Function):

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     constexpr int WF = (WTOT + T - 1) / T;
     constexpr int STAGE = (BM + BN) * LDT;
 
-    __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
+    constexpr int EPI = (BN / 32) * BM + 512 + NW * 32 * 36;      // epilogue scratch: GroupNorm partials + per-wave patches
+    constexpr int SMEM = ((DB ? 2 : 1) * STAGE > EPI) ? (DB ? 2 : 1) * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                       (!res || rfast);
     constexpr int TLD = 36;
     constexpr int SCR = (BN / 32) * BM + 512;                // GroupNorm scratch (P + stats, N >= 4) lives below the patches
-    static_assert(SCR + NW * 32 * TLD <= (DB ? 2 : 1) * STAGE, "epilogue scratch must fit in the staging buffer");
+    static_assert(SCR + NW * 32 * TLD <= SMEM, "epilogue scratch must fit in the LDS allocation");
     float* patch = smem + SCR + wave * (32 * TLD);
     const int tr = lane >> 3, cq = lane & 7;
 
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                             int64_t ssrow = tok;
                             if (p.ss_mode == DSC_SS_PER_SCENE) ssrow = tok / N;
                             else if (p.ss_mode == DSC_SS_PER_SLOT) ssrow = tok % N;
+                            else if (p.ss_mode == DSC_SS_BY_INDEX) ssrow = p.ss_index[tok / N];
                             const float* ss = p.scale_shift + ssrow * p.ld_ss;
                             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss + c);
                             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + p.n + c);

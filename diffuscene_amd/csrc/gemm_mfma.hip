@@ -33,26 +33,36 @@ int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
 
 }  // namespace
 
+// Tile choice: estimated time ~ ceil(blocks / 256 CUs) * tile area (every CU works through its blocks); ties go to the
+// larger tile (fewer LDS-staged bytes per MFMA).
+static long tile_cost(long m_rows, int rows_per_blk, int n, int bm, int bn) {
+    const long nblk = ((m_rows + rows_per_blk - 1) / rows_per_blk) * ((n + bn - 1) / bn);
+    return ((nblk + 255) / 256) * (long)bm * bn;
+}
+
 extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
     int rc = check_common(a);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // pick the token-tile height that wastes the fewest padded rows (ties -> taller tile)
-    const int cand[3] = {160, 128, 96};
-    int best = 160;
-    long best_cost = -1;
-    for (int i = 0; i < 3; ++i) {
-        const long cost = (long)((a->m + cand[i] - 1) / cand[i]) * cand[i];
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[i]; }
+    const bool wide = (a->n % 256) == 0 && (a->k1 % 64) == 0 && (a->k2 % 64) == 0;
+    struct Cand { int bm, bn, id; };
+    const Cand cands[5] = {{160, 256, 0}, {160, 128, 1}, {128, 128, 2}, {96, 128, 3}, {64, 64, 4}};
+    int best = -1;
+    long best_cost = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (cands[i].id == 0 && !wide) continue;
+        const long c = tile_cost(a->m, cands[i].bm, a->n, cands[i].bm, cands[i].bn) * a->batch;
+        if (best < 0 || c < best_cost) { best = cands[i].id; best_cost = c; }
     }
-    if (best == 160) {
+    switch (best) {
         // 8 waves x (5x1 tiles): 160 x 256 block tile, one block per CU -- fewer LDS-staged bytes per MFMA (measured
         // +10 % over the 4-wave 160 x 128 tile on M=20480, n=512); needs full 256-column tiles and K tiles of 64
-        if ((a->n % 256) == 0 && (a->k1 % 64) == 0 && (a->k2 % 64) == 0) return launch<5, 1, 1, 8, false, 64>(a, 160, s);
-        return launch<5, 1, 1, 4, false>(a, 160, s);
+        case 0: return launch<5, 1, 1, 8, false, 64>(a, 160, s);
+        case 1: return launch<5, 1, 1, 4, false>(a, 160, s);
+        case 2: return launch<2, 2, 2, 2, false>(a, 128, s);
+        case 3: return launch<3, 1, 1, 4, false>(a, 96, s);
+        default: return launch<1, 1, 2, 2, false>(a, 64, s);
     }
-    if (best == 128) return launch<2, 2, 2, 2, false>(a, 128, s);
-    return launch<3, 1, 1, 4, false>(a, 96, s);
 }
 
 extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
@@ -69,20 +79,27 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
     if (a->ss_mode != DSC_SS_NONE) {
         if (!a->scale_shift) return DSC_EINVAL;
         if (!dsc_aligned16(a->scale_shift) || (a->ld_ss & 3)) return DSC_EALIGN;
-        if (a->ss_mode < DSC_SS_NONE || a->ss_mode > DSC_SS_PER_SLOT) return DSC_EINVAL;
+        if (a->ss_mode < DSC_SS_NONE || a->ss_mode > DSC_SS_BY_INDEX) return DSC_EINVAL;
+        if (a->ss_mode == DSC_SS_BY_INDEX && !a->ss_index) return DSC_EINVAL;
     } else if (a->scale_shift) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int cand[3] = {160, 128, 96};
-    int best = 0;
-    double best_u = -1.0;
-    for (int i = 0; i < 3; ++i) {
-        if (cand[i] < N) continue;
-        const double u = (double)((cand[i] / N) * N) / cand[i];
-        if (u > best_u + 1e-9) { best_u = u; best = cand[i]; }
+    // scene-aligned tiles: a block holds floor(BM / N) whole scenes; padded rows are wasted MFMA work
+    struct Cand { int bm, bn; };
+    const Cand cands[4] = {{160, 128}, {128, 128}, {96, 128}, {64, 64}};
+    int best = -1;
+    long best_cost = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (cands[i].bm < N) continue;
+        const int rpb = (cands[i].bm / N) * N;
+        const long c = tile_cost(a->m, rpb, a->n, cands[i].bm, cands[i].bn);
+        if (best < 0 || c < best_cost) { best = i; best_cost = c; }
     }
-    if (!best) return DSC_ERANGE;
-    const int rpb = (best / N) * N;
-    if (best == 160) return launch<5, 1, 1, 4, true>(a, rpb, s);
-    if (best == 128) return launch<2, 2, 2, 2, true>(a, rpb, s);
-    return launch<3, 1, 1, 4, true>(a, rpb, s);
+    if (best < 0) return DSC_ERANGE;
+    const int rpb = (cands[best].bm / N) * N;
+    switch (best) {
+        case 0: return launch<5, 1, 1, 4, true>(a, rpb, s);
+        case 1: return launch<2, 2, 2, 2, true>(a, rpb, s);
+        case 2: return launch<3, 1, 1, 4, true>(a, rpb, s);
+        default: return launch<1, 1, 2, 2, true>(a, rpb, s);
+    }
 }

@@ -26,6 +26,7 @@ struct TnArgs {
     const float* a2; long lda2; int k2;       // optional second channel segment
     const float* dy; long ldd;
     float* out; long ldo;                     // [n][k1+k2] (or slab s at out + s*slab)
+    float* bias_out;                          // optional: column sums of dy (bias gradient), [n] (or slab s)
     long slab;                                // elements between split slabs (0 when splits == 1)
     int m, n, kvalid;                         // kvalid: columns >= kvalid are not stored (padded small-K inputs)
     int chunk;                                // tokens per split (multiple of 32)
@@ -59,6 +60,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    const bool do_bias = p.bias_out && it == 0 && tid < 128;   // the first k-tile column of blocks also owns the bias gradient
+    float bsum = 0.f;
     f32x4 ar[4], br[4];
     auto load_tile = [&](long m0) {
 #pragma unroll
@@ -88,6 +91,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
             store_tile();
             __syncthreads();
             if (m0 + TN_BK < m_end) load_tile(m0 + TN_BK);
+            if (do_bias) {
+#pragma unroll
+                for (int r = 0; r < TN_BK; ++r) bsum += Bs[r * TN_LD + tid];
+            }
 #pragma unroll
             for (int s = 0; s < TN_BK / 2; ++s) {
                 float af[2], bf[2];
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
         }
     }
     float* out = p.out + (long)split * p.slab;
+    if (do_bias && j0 + tid < p.n) p.bias_out[(long)split * p.slab + j0 + tid] = bsum;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int j = j0 + (wj * 2 + b) * 32 + l31;          // output row (n)
@@ -164,7 +172,8 @@ struct GnBwdArgs {
     const float* gamma; const float* beta;
     const float* ss; long ld_ss; int ss_mode;
     float* dz; long lddz;
-    float* dgamma_p; float* dbeta_p; float* dbias_p;     // [scenes][C]
+    float* dgamma_p; float* dbeta_p; float* dbias_p;     // [scenes][...] rows pstride floats apart
+    long pstride;
     float* dss; long ld_dss;                              // per-scene: [scenes][2C]; per-token/slot: [M][2C]
     int n_tok, C; float eps;
 };
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const GnBwdArgs p) {
     csum[0][tq][cl] = Gg; csum[1][tq][cl] = Gb; csum[2][tq][cl] = Gz; csum[3][tq][cl] = Gsc; csum[4][tq][cl] = Gsh;
     __syncthreads();
     if (tq == 0) {
-        const long o = (long)b * p.C + c;
+        const long o = (long)b * p.pstride + c;
         p.dgamma_p[o] = (csum[0][0][cl] + csum[0][1][cl]) + (csum[0][2][cl] + csum[0][3][cl]);
         p.dbeta_p[o] = (csum[1][0][cl] + csum[1][1][cl]) + (csum[1][2][cl] + csum[1][3][cl]);
         p.dbias_p[o] = (csum[2][0][cl] + csum[2][1][cl]) + (csum[2][2][cl] + csum[2][3][cl]);
@@ -648,8 +657,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }  // namespace
 
 // --------------------------------------------------------------------------------------------- C ABI
+static void tn_split(int m, int n, int k, int* splits, int* chunk) {
+    const int ktiles = (k + 127) / 128, ntiles = (n + 127) / 128;
+    int s = (512 + ktiles * ntiles - 1) / (ktiles * ntiles);        // aim at ~2 blocks per CU
+    const int maxs = (m + 31) / 32;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    *chunk = ((m + s - 1) / s + 31) / 32 * 32;
+    *splits = (m + *chunk - 1) / *chunk;
+}
+
 extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const float* a2, int64_t lda2, int32_t k2,
-                               const float* dy, int64_t ldd, float* out, int64_t ldo, int32_t m, int32_t n,
+                               const float* dy, int64_t ldd, float* out, int64_t ldo, float* dbias, int32_t m, int32_t n,
                                int32_t kvalid, float* workspace, int64_t workspace_floats, dsc_stream_t stream) {
     if (!a1 || !dy || !out || m < 1 || n < 1 || k1 < 1 || k2 < 0 || (k2 > 0 && !a2)) return DSC_EINVAL;
     if ((k1 & 3) || (k2 & 3) || (n & 3)) return DSC_EINVAL;
@@ -659,41 +678,39 @@ extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const 
     const int K = k1 + k2;
     if (kvalid < 1 || kvalid > K) return DSC_EINVAL;
     const int ktiles = (K + 127) / 128, ntiles = (n + 127) / 128;
-    int splits = (768 + ktiles * ntiles - 1) / (ktiles * ntiles);
-    const int maxs = (m + 31) / 32;
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
-    int chunk = ((m + splits - 1) / splits + 31) / 32 * 32;
-    splits = (m + chunk - 1) / chunk;
-    const long slab = (long)n * ldo;
+    int splits, chunk;
+    tn_split(m, n, K, &splits, &chunk);
+    const long wslab = (long)n * ldo;                                  // weight-gradient part of a slab
+    const long slab = wslab + n;                                       // + bias-gradient row
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TnArgs p{a1, (long)lda1, k1, a2, (long)lda2, k2, dy, (long)ldd, out, (long)ldo, 0, m, n, kvalid, chunk, ktiles};
+    TnArgs p{a1, (long)lda1, k1, a2, (long)lda2, k2, dy, (long)ldd, out, (long)ldo, dbias, 0, m, n, kvalid, chunk, ktiles};
     if (splits > 1) {
         if (!workspace || workspace_floats < slab * splits) return DSC_EINVAL;
         if (ldo != kvalid) return DSC_EINVAL;                          // slab reduction assumes a dense [n][kvalid] output
         p.out = workspace;
+        p.bias_out = dbias ? workspace + wslab : nullptr;
         p.slab = slab;
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(ktiles * ntiles, splits), dim3(256), 0, s, p);
     DSC_LAUNCH_CHECK();
     if (splits > 1) {
-        long blocks = (slab + 255) / 256;
+        long blocks = (wslab + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, slab, splits, out, slab);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, slab, splits, out, wslab);
         DSC_LAUNCH_CHECK();
+        if (dbias) {
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace + wslab, slab, splits,
+                               dbias, (long)n);
+            DSC_LAUNCH_CHECK();
+        }
     }
     return 0;
 }
 
 extern "C" int64_t dsc_gemm_tn_workspace_floats(int32_t m, int32_t n, int32_t k) {
-    const int ktiles = (k + 127) / 128, ntiles = (n + 127) / 128;
-    int splits = (768 + ktiles * ntiles - 1) / (ktiles * ntiles);
-    const int maxs = (m + 31) / 32;
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
-    int chunk = ((m + splits - 1) / splits + 31) / 32 * 32;
-    splits = (m + chunk - 1) / chunk;
-    return splits > 1 ? (int64_t)n * k * splits : 0;
+    int splits, chunk;
+    tn_split(m, n, k, &splits, &chunk);
+    return splits > 1 ? ((int64_t)n * k + n) * splits : 0;
 }
 
 extern "C" int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,
@@ -720,13 +737,14 @@ extern "C" int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n,
 extern "C" int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy, int64_t ldy, const float* gamma,
                                    const float* beta, const float* scale_shift, int64_t ld_ss, int32_t ss_mode,
                                    float* dz, int64_t lddz, float* dgamma_p, float* dbeta_p, float* dbias_p,
-                                   float* dss, int64_t ld_dss, int32_t scenes, int32_t tokens_per_scene, int32_t channels,
-                                   float eps, dsc_stream_t stream) {
+                                   int64_t partial_stride, float* dss, int64_t ld_dss, int32_t scenes,
+                                   int32_t tokens_per_scene, int32_t channels, float eps, dsc_stream_t stream) {
     if (!z || !dy || !gamma || !beta || !dz || !dgamma_p || !dbeta_p || !dbias_p) return DSC_EINVAL;
     if (scenes < 1 || tokens_per_scene < 1 || channels != 512) return DSC_ERANGE;
     if (ss_mode != DSC_SS_NONE && !scale_shift) return DSC_EINVAL;
     GnBwdArgs p{z, (long)ldz, dy, (long)ldy, gamma, beta, ss_mode != DSC_SS_NONE ? scale_shift : nullptr, (long)ld_ss,
-                ss_mode, dz, (long)lddz, dgamma_p, dbeta_p, dbias_p, dss, (long)ld_dss, tokens_per_scene, channels, eps};
+                ss_mode, dz, (long)lddz, dgamma_p, dbeta_p, dbias_p, (long)partial_stride, dss, (long)ld_dss, tokens_per_scene,
+                channels, eps};
     hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(scenes * 8), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     DSC_LAUNCH_CHECK();
     return 0;

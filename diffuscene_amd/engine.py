@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, SS_NONE, SS_PER_SCENE, SS_PER_SLOT, SS_PER_TOKEN
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, SS_BY_INDEX, SS_NONE, SS_PER_SCENE, SS_PER_SLOT, SS_PER_TOKEN
 
 D = 512
 HID = 128
@@ -45,7 +45,7 @@ class _Pool:
 class Plan:
     """Static launch list for one (B, N, conditioning) signature."""
 
-    def __init__(self, eng, B, N, ctx_mode, ctx_dim, L, text_dim):
+    def __init__(self, eng, B, N, ctx_mode, ctx_dim, L, text_dim, time_table=False):
         self.eng, self.B, self.N, self.M = eng, B, N, B * N
         dev = eng.device
         self.pool = _Pool(dev)
@@ -60,6 +60,7 @@ class Plan:
         self.cross_in = torch.empty((B * L, text_dim), device=dev, dtype=torch.float32) if L else None
         self.ctx_mode = ctx_mode
         self.L = L
+        self.time_table = time_table
         self.out = torch.empty((self.M, net.out_dim), device=dev, dtype=torch.float32)
         self._build()
 
@@ -72,7 +73,8 @@ class Plan:
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, a2=None, ss=None, ss_mode=SS_NONE, residual=None):
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5,
-                               tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE)
+                               tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
+                               ss_index=self.t_in if ss_mode == SS_BY_INDEX else None)
         self.keep.append((g, a, w, out, bias, a2, residual, gamma, beta, ss))
         self.steps.append((_lib.fn("dsc_gemm_gn_silu_f32"), (C.byref(g),)))
         return out
@@ -109,7 +111,7 @@ class Plan:
 
     def t_ss(self, rb):
         i = self.eng.t_index[id(rb)]
-        return self.ss_t[:, i * 2 * D:(i + 1) * 2 * D], SS_PER_SCENE
+        return self.ss_t[:, i * 2 * D:(i + 1) * 2 * D], (SS_BY_INDEX if self.time_table else SS_PER_SCENE)
 
     def c_ss(self, rb):
         if self.ss_c is None:
@@ -181,13 +183,19 @@ class Plan:
         e, net, M, B = self.eng, self.eng.net, self.M, self.B
         pool = self.pool
         # ---- conditioning: time MLP, then all 19 per-block Linear(2048->1024) as ONE GEMM ----------
-        temb = pool.get(B, D)
-        self.call("dsc_time_embedding_f32", self.t_in.data_ptr(), B, D, e.time_table.data_ptr(), e.time_table.shape[0],
-                  e.time_freq.data_ptr(), temb.data_ptr(), keep=(temb,))
-        t1 = self.gemm(temb, net.time_mlp[1].weight, pool.get(B, 4 * D), net.time_mlp[1].bias, act_out=ACT_GELU)
-        # every consumer applies SiLU first (ResnetBlock.mlp) -> fold it into this epilogue
-        t2 = self.gemm(t1, net.time_mlp[3].weight, pool.get(B, 4 * D), net.time_mlp[3].bias, act_out=ACT_SILU)
-        self.ss_t = self.gemm(t2, e.t_pack_w, pool.get(B, e.t_pack_w.shape[0]), e.t_pack_b)
+        if self.time_table:
+            # sampling: every (scale, shift) row depends on the integer timestep only -> one table row per timestep,
+            # computed once per weight version by the same GEMMs (DenoiserEngine.ss_table); the per-step time MLP
+            # (3 GEMMs, M = B) disappears and the epilogue gathers row t[scene]
+            self.ss_t = e.ss_table()
+        else:
+            temb = pool.get(B, D)
+            self.call("dsc_time_embedding_f32", self.t_in.data_ptr(), B, D, e.time_table.data_ptr(),
+                      e.time_table.shape[0], e.time_freq.data_ptr(), temb.data_ptr(), keep=(temb,))
+            t1 = self.gemm(temb, net.time_mlp[1].weight, pool.get(B, 4 * D), net.time_mlp[1].bias, act_out=ACT_GELU)
+            # every consumer applies SiLU first (ResnetBlock.mlp) -> fold it into this epilogue
+            t2 = self.gemm(t1, net.time_mlp[3].weight, pool.get(B, 4 * D), net.time_mlp[3].bias, act_out=ACT_SILU)
+            self.ss_t = self.gemm(t2, e.t_pack_w, pool.get(B, e.t_pack_w.shape[0]), e.t_pack_b)
         if self.ctx_in is not None:
             self.ss_c = self.gemm(self.ctx_in, e.c_pack_w, pool.get(self.ctx_in.shape[0], e.c_pack_w.shape[0]),
                                   e.c_pack_b, act_in=ACT_SILU)
@@ -362,23 +370,43 @@ class DenoiserEngine:
                     self.c_pack_w[i * 2 * D:(i + 1) * 2 * D].copy_(rb.mlp[1].weight)
                     self.c_pack_b[i * 2 * D:(i + 1) * 2 * D].copy_(rb.mlp[1].bias)
         self.sig = sig
+        self._ss_table_sig = None          # the per-timestep table is stale now (recomputed in place on demand)
 
-    def plan_for(self, B, N, ctx_mode, ctx_dim, L, text_dim):
-        key = (B, N, ctx_mode, ctx_dim, L, text_dim)
+    def ss_table(self):
+        """(scale, shift) of all 19 time-conditioned blocks for every tabulated timestep: [T, 19*1024].  Row t is what the
+        per-step time MLP produces for t (same kernels, rows are independent), so sampling results do not change."""
+        T = self.time_table.shape[0]
+        if getattr(self, "_ss_table", None) is None:
+            self._ss_table = torch.empty((T, self.t_pack_w.shape[0]), device=self.device)
+            self._ss_table_sig = None
+        if self._ss_table_sig != self.sig:
+            net = self.net
+            with torch.no_grad():
+                t1 = ops.gemm(self.time_table, net.time_mlp[1].weight, net.time_mlp[1].bias, act_out=ACT_GELU)
+                t2 = ops.gemm(t1, net.time_mlp[3].weight, net.time_mlp[3].bias, act_out=ACT_SILU)
+                ops.gemm(t2, self.t_pack_w, self.t_pack_b, out=self._ss_table)
+            self._ss_table_sig = self.sig
+        return self._ss_table
+
+    def plan_for(self, B, N, ctx_mode, ctx_dim, L, text_dim, time_table=False):
+        key = (B, N, ctx_mode, ctx_dim, L, text_dim, time_table)
         p = self.plans.get(key)
         if p is None:
             if N > _lib.MAX_TOKENS_PER_SCENE:
                 raise RuntimeError("diffuscene_amd: at most %d objects per scene are supported by the fused "
                                    "GroupNorm / attention kernels (got %d)" % (_lib.MAX_TOKENS_PER_SCENE, N))
-            p = Plan(self, B, N, ctx_mode, ctx_dim, L, text_dim)
+            p = Plan(self, B, N, ctx_mode, ctx_dim, L, text_dim, time_table)
             self.plans[key] = p
         return p
 
     @torch.no_grad()
-    def prepare(self, B, N, context, context_cross, refresh=True):
-        """Select / build the plan for this signature and upload the step-invariant conditioning."""
+    def prepare(self, B, N, context, context_cross, refresh=True, time_table=False):
+        """Select / build the plan for this signature and upload the step-invariant conditioning.
+        time_table=True (reverse loops: integer timesteps below the table size) replaces the time MLP by a table."""
         if refresh:
             self.refresh()
+        if time_table:
+            self.ss_table()
         ctx_mode, ctx_dim = SS_NONE, 0
         if context is not None and self.c_pack_w is not None:
             ctx_dim = context.shape[-1]
@@ -388,7 +416,7 @@ class DenoiserEngine:
         L = text_dim = 0
         if context_cross is not None and self.net.text_condition:
             L, text_dim = context_cross.shape[1], context_cross.shape[2]
-        p = self.plan_for(B, N, ctx_mode, ctx_dim, L, text_dim)
+        p = self.plan_for(B, N, ctx_mode, ctx_dim, L, text_dim, time_table)
         if ctx_mode != SS_NONE:
             p.ctx_in.copy_(context[0] if ctx_mode == SS_PER_SLOT else context.reshape(B * N, ctx_dim))
         if L:

@@ -40,7 +40,8 @@ def as2d(w):
 
 
 def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
-                   gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None):
+                   gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None,
+                   ss_index=None):
     """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
     pointers only; the caller keeps the tensors alive."""
     g = GemmArgs()
@@ -72,6 +73,8 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         g.ss_mode = ss_mode
     if preact is not None:
         g.preact, g.ld_preact = _mat(preact, "preact")
+    if ss_index is not None:
+        g.ss_index = _dev(ss_index, "ss_index", torch.int64).data_ptr()
     return g
 
 
@@ -270,8 +273,8 @@ def transpose(w, out=None, ldo=None):
     return out
 
 
-def gemm_tn(a, dy, a2=None, kvalid=None, out=None):
-    """out[n][k] = sum_m dy[m][n] * [a|a2][m][k]"""
+def gemm_tn(a, dy, a2=None, kvalid=None, out=None, want_bias=False):
+    """out[n][k] = sum_m dy[m][n] * [a|a2][m][k]  (+ column sums of dy when want_bias) -> out or (out, dbias)"""
     ap, lda = _mat(a, "a")
     dp, ldd = _mat(dy, "dy")
     k1 = a.shape[1]
@@ -287,10 +290,12 @@ def gemm_tn(a, dy, a2=None, kvalid=None, out=None):
     op, ldo = _mat(out, "out")
     wsf = _lib.fn("dsc_gemm_tn_workspace_floats")(m, n, kv)
     ws = scratch(a.device, wsf) if wsf else None
-    _lib.check(_lib.fn("dsc_gemm_tn_f32")(ap, lda, k1, a2p, lda2, k2, dp, ldd, op, ldo, m, n, kv,
+    db = torch.empty((n,), device=a.device, dtype=torch.float32) if want_bias else None
+    _lib.check(_lib.fn("dsc_gemm_tn_f32")(ap, lda, k1, a2p, lda2, k2, dp, ldd, op, ldo,
+                                          db.data_ptr() if want_bias else None, m, n, kv,
                                           ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
                                           stream_ptr()), "dsc_gemm_tn_f32")
-    return out
+    return (out, db) if want_bias else out
 
 
 def colsum(x, out=None):
@@ -310,7 +315,7 @@ def gn_silu_bwd(z, dy, gamma, beta, ss, ss_mode, scenes, n_tok, eps=1e-5):
     dp, ldy = _mat(dy, "dy")
     M, Cc = z.shape
     dz = torch.empty((M, Cc), device=z.device, dtype=torch.float32)
-    part = torch.empty((3, scenes, Cc), device=z.device, dtype=torch.float32)
+    part = torch.empty((scenes, 3 * Cc), device=z.device, dtype=torch.float32)     # [dgamma | dbeta | dbias] per scene
     dss = None
     sp, ld_ss, ld_dss = None, 0, 0
     if ss is not None and ss_mode != SS_NONE:
@@ -318,15 +323,12 @@ def gn_silu_bwd(z, dy, gamma, beta, ss, ss_mode, scenes, n_tok, eps=1e-5):
         dss = torch.empty((scenes if ss_mode == SS_PER_SCENE else M, 2 * Cc), device=z.device, dtype=torch.float32)
         ld_dss = 2 * Cc
     _lib.check(_lib.fn("dsc_gn_silu_bwd_f32")(zp, ldz, dp, ldy, _dev(gamma).data_ptr(), _dev(beta).data_ptr(), sp, ld_ss,
-                                              ss_mode if sp else SS_NONE, dz.data_ptr(), Cc, part[0].data_ptr(),
-                                              part[1].data_ptr(), part[2].data_ptr(),
+                                              ss_mode if sp else SS_NONE, dz.data_ptr(), Cc, part.data_ptr(),
+                                              part.data_ptr() + 4 * Cc, part.data_ptr() + 8 * Cc, 3 * Cc,
                                               dss.data_ptr() if dss is not None else None, ld_dss, scenes, n_tok, Cc,
                                               eps, stream_ptr()), "dsc_gn_silu_bwd_f32")
-    # column-sums over the scenes for the three per-channel gradients
-    red = torch.empty((3, Cc), device=z.device, dtype=torch.float32)
-    for i in range(3):
-        colsum(part[i], out=red[i])
-    return dz, red[0], red[1], red[2], dss
+    red = colsum(part)                  # one column sum over the scenes for the three per-channel gradients
+    return dz, red[:Cc], red[Cc:2 * Cc], red[2 * Cc:], dss
 
 
 def weight_standardize_bwd(weights, dw_stds, eps=1e-5):

@@ -35,7 +35,8 @@ class _StepGraph:
         B, N, C = shape
         self.shape = shape
         eng = model.engine(device)
-        self.plan = eng.prepare(B, N, condition, condition_cross)
+        use_table = diff.num_timesteps <= eng.time_table.shape[0]
+        self.plan = eng.prepare(B, N, condition, condition_cross, time_table=use_table)
         tb = diff.tables(device)
         ca, cb = diff._coeffs(tb)
         self.x = torch.empty(shape, device=device, dtype=torch.float32)
@@ -102,7 +103,7 @@ def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cros
             g = _StepGraph(diff, model, tuple(shape), device, condition, condition_cross, clip_denoised, replay)
             diff._graphs = {key: g}           # one live graph per diffusion object
         else:
-            eng.prepare(shape[0], shape[1], condition, condition_cross)   # refresh weights + conditioning buffers
+            eng.prepare(shape[0], shape[1], condition, condition_cross, time_table=g.plan.time_table)   # refresh weights + conditioning
         if replay:
             return g.run(noise_fn.buffer[0], total_steps, noise_fn.buffer)
         x_T = torch.randn(shape, dtype=torch.float, device=device)
@@ -112,4 +113,4 @@ def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cros
 def _plan_key(g):
     p = g.plan
     return (p.B, p.N, p.ctx_mode, 0 if p.ctx_in is None else p.ctx_in.shape[1], p.L,
-            0 if p.cross_in is None else p.cross_in.shape[1])
+            0 if p.cross_in is None else p.cross_in.shape[1], p.time_table)

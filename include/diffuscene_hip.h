@@ -38,6 +38,7 @@ typedef void* dsc_stream_t; /* hipStream_t */
 #define DSC_SS_PER_TOKEN 1   /* scale_shift row = token           (context-conditioned ResnetBlock) */
 #define DSC_SS_PER_SCENE 2   /* scale_shift row = token / N       (time-conditioned ResnetBlock)    */
 #define DSC_SS_PER_SLOT  3   /* scale_shift row = token % N       (instance embedding shared over B)*/
+#define DSC_SS_BY_INDEX  4   /* scale_shift row = ss_index[token / N]  (per-timestep table while sampling) */
 
 #define DSC_HEADS    4
 #define DSC_DIM_HEAD 32
@@ -69,6 +70,7 @@ typedef struct dsc_gemm_args {
     int32_t tokens_per_scene;                    /* N: GroupNorm reduces over 64 channels x N tokens (:164) */
     const float* scale_shift; int64_t ld_ss; int32_t ss_mode; /* row layout [scale(n) | shift(n)] */
     float* preact; int64_t ld_preact;            /* optional: pre-norm conv output z = [A1|A2].W^T + bias, saved for backward */
+    const int64_t* ss_index;                     /* DSC_SS_BY_INDEX: device int64 per scene (the timestep vector t) */
 } dsc_gemm_args;
 
 int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
@@ -166,8 +168,8 @@ int dsc_complete_overwrite_f32(float* x, const float* partial, const float* nois
  * two-stage reduction through `workspace`, sized by dsc_gemm_tn_workspace_floats).  Columns >= kvalid of a
  * zero-padded small-K input are not stored; out is dense [n][kvalid] (ldo == kvalid) when split. */
 int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const float* a2, int64_t lda2, int32_t k2,
-                    const float* dy, int64_t ldd, float* out, int64_t ldo, int32_t m, int32_t n, int32_t kvalid,
-                    float* workspace, int64_t workspace_floats, dsc_stream_t stream);
+                    const float* dy, int64_t ldd, float* out, int64_t ldo, float* dbias /* [n] column sums of dy, or NULL */,
+                    int32_t m, int32_t n, int32_t kvalid, float* workspace, int64_t workspace_floats, dsc_stream_t stream);
 int64_t dsc_gemm_tn_workspace_floats(int32_t m, int32_t n, int32_t k);
 
 /* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */
@@ -176,11 +178,11 @@ int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out
 
 /* Backward of the GroupNorm + (scale+1, shift) + SiLU epilogue of dsc_gemm_gn_silu_f32 (Block.forward,
  * denoise_net.py:167-176) from the saved pre-norm output z.  dz feeds the GEMM backward; dgamma_p / dbeta_p /
- * dbias_p are per-scene partials [scenes][512] (reduce with dsc_colsum_f32); dss is [scenes][1024] for
+ * dbias_p are per-scene partials, row b at p + b*partial_stride (reduce with dsc_colsum_f32); dss is [scenes][1024] for
  * DSC_SS_PER_SCENE, [m][1024] for PER_TOKEN / PER_SLOT (caller reduces over the batch for PER_SLOT). */
 int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy, int64_t ldy, const float* gamma,
                         const float* beta, const float* scale_shift, int64_t ld_ss, int32_t ss_mode,
-                        float* dz, int64_t lddz, float* dgamma_p, float* dbeta_p, float* dbias_p,
+                        float* dz, int64_t lddz, float* dgamma_p, float* dbeta_p, float* dbias_p, int64_t partial_stride,
                         float* dss, int64_t ld_dss, int32_t scenes, int32_t tokens_per_scene, int32_t channels,
                         float eps, dsc_stream_t stream);
 

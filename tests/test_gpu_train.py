@@ -173,12 +173,81 @@ def test_attention_cores_backward(B, N):
     assert rel(gq.grad, qd.grad) < 1e-5 and rel(gkv.grad, kvd.grad) < 1e-5
 
 
+def _oracle_grad_norms_fp64(kw, x, t, cond, noise, names, cross=None, iou=True):
+    """Gradient norms of the p_losses objective evaluated in float64 by the oracle restatement (eps stays 1e-5)."""
+    sd = {k: v.double().requires_grad_(True) for k, v in W.synth_state_dict(kw).items()}
+    tb = {k: v.double() for k, v in R.schedule_tables(1e-4, 0.02, 1000, "v").items()}
+    emb = R.sinusoidal_embedding
+    R.sinusoidal_embedding = lambda tt, dim: emb(tt, dim).double()
+    cd = cross.double() if cross is not None else None
+    try:
+        lw, _, _ = R.p_losses(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond.double(), cd), x.double(), t,
+                              noise.double(), R.dims_from_kwargs(kw), True, iou, W.DATASET_STATS)
+        lw.mean().backward()
+    finally:
+        R.sinusoidal_embedding = emb
+    return np.array([float(sd[k].grad.norm()) for k in names]), lw.detach()
+
+
+def test_text_conditioned_training_gradients_vs_fp64():
+    """config/text (cross-attention on 512-d text tokens): loss and every parameter gradient of the
+    HIP path against the fp64 oracle; also gradients w.r.t. the conditioning inputs."""
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    kw, x, t, cond, cross = case_inputs("text_bedroom")
+    net = Unet1D(**kw)
+    net.load_state_dict(W.synth_state_dict(kw))
+    net.to(dev())
+    cfg = dict(objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32)
+    diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=False)
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    gc, gx = cond.to(dev()).requires_grad_(True), cross.to(dev()).requires_grad_(True)
+    losses, _ = diff.diffusion.p_losses(diff._denoise, x.to(dev()), t.to(dev()), noise=noise.to(dev()), condition=gc,
+                                        condition_cross=gx)
+    losses.mean().backward()
+    names = [k for k, _ in net.named_parameters()]
+    truth, lw = _oracle_grad_norms_fp64(kw, x, t, cond, noise, names, cross=cross, iou=False)
+    assert rel(losses, lw) < 1e-5
+    gn = np.array([float(p.grad.norm()) for _, p in net.named_parameters()])
+    err = np.abs(gn - truth) / np.maximum(truth, 1e-3 * truth.max())
+    print("text model: grad-norm rel err vs fp64 max %.3g at %s" % (err.max(), names[int(err.argmax())]))
+    assert err.max() < 1e-4
+    assert gc.grad is not None and gx.grad is not None and float(gx.grad.abs().sum()) > 0
+
+
+def test_rearrange_training_loss_path():
+    """config/rearrange: 5 diffused channels, non-separate init/final conv, 512-d per-token conditioning, arrange loss."""
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    kw, x, t, cond, _ = case_inputs("rearrange_living")
+    net = Unet1D(**kw)
+    net.load_state_dict(W.synth_state_dict(kw))
+    net.to(dev())
+    cfg = dict(objectness_dim=0, class_dim=25, angle_dim=2, objfeat_dim=32, room_arrange_condition=True)
+    diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=False)
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    losses, scal = diff.diffusion.p_losses(diff._denoise, x.to(dev()), t.to(dev()), noise=noise.to(dev()),
+                                           condition=cond.to(dev()), condition_cross=None)
+    losses.mean().backward()
+    assert set(scal) == {"loss.trans", "loss.angle"}
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    with torch.no_grad():
+        xt = R.q_sample(tb, x, t, noise)
+        out = R.unet1d_forward(sd, kw, xt, t, cond, None)
+        tgt = R.predict_v(tb, x, t, noise)
+        ref = (((tgt[:, :, :3] - out[:, :, :3]) ** 2).mean((1, 2)) + ((tgt[:, :, 3:] - out[:, :, 3:]) ** 2).mean((1, 2))) \
+            * tb["loss_weight"][t]
+    assert rel(losses, ref) < 1e-4
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
 @pytest.mark.parametrize("name", ["uncond_bedroom", "uncond_living"])
 def test_training_gradients_match_reference(golden_dir, tmp_path, name):
-    """p_losses (+IoU term) and the gradient of EVERY parameter vs the real reference (golden): losses and committed
-    gradient slices within 1e-4; per-parameter gradient norms of all 442 tensors within 1e-3 (measured: <3e-5 everywhere
-    except time_mlp.3.weight at 2.6e-4, whose gradient is a K=19456 fp32 reduction with heavy cancellation -- fp32
-    summation-order noise of that size is present in the reference itself)."""
+    """p_losses (+IoU term) and the gradient of EVERY parameter.  Losses and committed gradient slices vs the real
+    reference (golden) within 1e-4.  Gradient norms of all 442 tensors: the reference's own fp32 CPU result is up to
+    2.6e-4 away from an fp64 evaluation (time-MLP weights: long, cancelling reductions), so the HIP path is held to 1e-4
+    against the fp64 truth and to 1e-3 against the fp32 reference."""
     from diffuscene_amd.networks.denoise_net import Unet1D
     from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
     g = np.load(os.path.join(golden_dir, "p_losses.npz"))
@@ -202,11 +271,17 @@ def test_training_gradients_match_reference(golden_dir, tmp_path, name):
     params = dict(net.named_parameters())
     gn = np.array([float(params[k].grad.norm()) for k in names])
     ref = g[name + ".grad_norms"]
-    err = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
-    worst = int(err.argmax())
-    print("worst grad-norm rel err %.3g at %s" % (err[worst], names[worst]))
-    print('grad-norm rel err: max %.3g, 99th pct %.3g, median %.3g' % (err.max(), np.percentile(err, 99), np.median(err)))
-    assert err.max() < 1e-3 and np.percentile(err, 98) < 1e-4
+
+    def relerr(a, b):
+        return np.abs(a - b) / np.maximum(b, 1e-3 * b.max())
+
+    # fp64 evaluation of the same loss by the oracle (same eps rule): the arbiter between two fp32 implementations
+    truth, _ = _oracle_grad_norms_fp64(kw, x, t, cond, noise, names)
+    e_hip, e_ref = relerr(gn, truth), relerr(ref, truth)
+    print("grad-norm rel err vs fp64: HIP max %.3g (%s) | reference fp32 max %.3g (%s)" % (
+        e_hip.max(), names[int(e_hip.argmax())], e_ref.max(), names[int(e_ref.argmax())]))
+    assert e_hip.max() < 1e-4                      # the HIP path is held to 1e-4 against the fp64 truth
+    assert relerr(gn, ref).max() < 1e-3            # and stays within the reference's own fp32 noise (max 2.6e-4) of it
     assert rel(net.init_conv.bias.grad, g[name + ".grad.init_conv.bias"]) < 1e-4
     assert rel(net.mid_attn.fn.fn.to_qkv.weight.grad[:8, :16, 0], g[name + ".grad.mid_attn.to_qkv"]) < 1e-4
     assert rel(net.downs[0][0].block1.proj.weight.grad[:8, :16, 0], g[name + ".grad.downs0.block1.proj"]) < 1e-4
