@@ -96,103 +96,118 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Linear attention core, one 128-thread block per (scene, head); K/V head slices of the scene in LDS.
-//   LDS rows padded to 33 floats: column walks (softmax over tokens) are conflict-free.
+// Linear attention core, one 256-thread block per (scene, head); Q/K/V head slices of the scene in LDS
+// (rows padded to 36 floats: 16-byte aligned float4 rows, column walks spread over the banks).
+//   phase 1  k <- softmax over the tokens        8 threads per head channel
+//   phase 2  ctx[d][e] = sum_j k[j][d] v[j][e]   4 outputs per thread
+//   phase 3  q <- softmax over channels * scale; out[i][e] = sum_d ctx[d][e] q[i][d]   4 threads per token
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXTOK = 160;
-constexpr int HP = 33;
+constexpr int HP = 33;      // softmax-attention kernel below
+constexpr int LP = 36;
 
-__global__ __launch_bounds__(128) void linear_attention_kernel(const float* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(256) void linear_attention_kernel(const float* __restrict__ q, int64_t ldq,
                                                                const float* __restrict__ k, int64_t ldk,
                                                                const float* __restrict__ v, int64_t ldv,
                                                                float* __restrict__ out, int64_t ldo,
                                                                int nq, int nk, float scale) {
-    __shared__ float Ks[MAXTOK * HP];
-    __shared__ float Vs[MAXTOK * HP];
-    __shared__ float ctx[32 * HP];
-    __shared__ float cmax[32], cinv[32];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ks = lds;                      // [nk][LP]
+    float* Vs = Ks + nk * LP;             // [nk][LP]
+    float* Qs = Vs + nk * LP;             // [nq][LP]
+    float* ctx = Qs + nq * LP;            // [32][LP]
     const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
     const int tid = threadIdx.x;
     const float* kb = k + (int64_t)b * nk * ldk + h * 32;
     const float* vb = v + (int64_t)b * nk * ldv + h * 32;
-    // stage K and V (nk x 32 each): float4 per thread-iteration, 8 threads per token row
-    for (int f = tid; f < nk * 8; f += 128) {
+    const float* qb = q + (int64_t)b * nq * ldq + h * 32;
+    for (int f = tid; f < nk * 8; f += 256) {
         const int j = f >> 3, c4 = (f & 7) * 4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { Ks[j * HP + c4 + e] = kv[e]; Vs[j * HP + c4 + e] = vv[e]; }
+        *reinterpret_cast<f32x4*>(Ks + j * LP + c4) = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
+        *reinterpret_cast<f32x4*>(Vs + j * LP + c4) = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
+    }
+    for (int f = tid; f < nq * 8; f += 256) {
+        const int i = f >> 3, c4 = (f & 7) * 4;
+        *reinterpret_cast<f32x4*>(Qs + i * LP + c4) = *reinterpret_cast<const f32x4*>(qb + (int64_t)i * ldq + c4);
     }
     __syncthreads();
-    // softmax of k over the nk tokens, per head channel d: 4 threads per channel
-    {
-        const int d = tid >> 2, part = tid & 3;
+    {   // phase 1: softmax of k over the nk tokens; 8 consecutive lanes share a channel
+        const int d = tid >> 3, part = tid & 7;
         float mx = -INFINITY;
-        for (int j = part; j < nk; j += 4) mx = fmaxf(mx, Ks[j * HP + d]);
+        for (int j = part; j < nk; j += 8) mx = fmaxf(mx, Ks[j * LP + d]);
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
         float sm = 0.f;
-        for (int j = part; j < nk; j += 4) {
-            const float e = expf(Ks[j * HP + d] - mx);
-            Ks[j * HP + d] = e;
+        for (int j = part; j < nk; j += 8) {
+            const float e = expf(Ks[j * LP + d] - mx);
+            Ks[j * LP + d] = e;
             sm += e;
         }
         sm += __shfl_xor(sm, 1, 64);
         sm += __shfl_xor(sm, 2, 64);
-        if (part == 0) { cmax[d] = mx; cinv[d] = 1.0f / sm; }
-    }
-    __syncthreads();
-    // context[d][e] = sum_j softk[j][d] v[j][e]; thread -> (d, 8 consecutive e)
-    {
-        const int d = tid >> 2, e0 = (tid & 3) * 8;
-        float a[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = 0.f;
-        for (int j = 0; j < nk; ++j) {
-            const float kd = Ks[j * HP + d];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += kd * Vs[j * HP + e0 + e];
-        }
-        const float inv = cinv[d];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ctx[d * HP + e0 + e] = a[e] * inv;
-    }
-    __syncthreads();
-    // per query token: softmax over the 32 head channels, * scale, then out[e] = sum_d ctx[d][e] q[d]
-    for (int i = tid; i < nq; i += 128) {
-        const float* qr = q + ((int64_t)b * nq + i) * ldq + h * 32;
-        float qv[32];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(qr + c * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qv[c * 4 + e] = t4[e];
-        }
-        float mx = qv[0];
-#pragma unroll
-        for (int d = 1; d < 32; ++d) mx = fmaxf(mx, qv[d]);
-        float sm = 0.f;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) { qv[d] = expf(qv[d] - mx); sm += qv[d]; }
+        sm += __shfl_xor(sm, 4, 64);
         const float inv = 1.0f / sm;
+        for (int j = part; j < nk; j += 8) Ks[j * LP + d] *= inv;
+    }
+    __syncthreads();
+    {   // phase 2: context; thread -> (d, 4 consecutive e)
+        const int d = tid >> 3, e0 = (tid & 7) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < nk; ++j) {
+            const float kd = Ks[j * LP + d];
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * LP + e0);
 #pragma unroll
-        for (int d = 0; d < 32; ++d) qv[d] = qv[d] * inv * scale;
-        float o[32];
-#pragma unroll
-        for (int e = 0; e < 32; ++e) o[e] = 0.f;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            const float qd = qv[d];
-#pragma unroll
-            for (int e = 0; e < 32; ++e) o[e] += ctx[d * HP + e] * qd;
+            for (int e = 0; e < 4; ++e) a[e] += kd * vv[e];
         }
-        float* orow = out + ((int64_t)b * nq + i) * ldo + h * 32;
+        *reinterpret_cast<f32x4*>(ctx + d * LP + e0) = a;
+    }
+    __syncthreads();
+    // phase 3: 4 lanes per query token, each owns 8 channels / 8 outputs
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        const int i = i0 + (tid >> 2), part = tid & 3;
+        const bool ok = i < nq;
+        float qv[8];
+        float mx = -INFINITY;
+        if (ok) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + i * LP + part * 8);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(Qs + i * LP + part * 8 + 4);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            f32x4 t4;
+            for (int e = 0; e < 4; ++e) { qv[e] = a[e]; qv[4 + e] = c[e]; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t4[e] = o[c * 4 + e];
-            *reinterpret_cast<f32x4*>(orow + c * 4) = t4;
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, qv[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float sm = 0.f;
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qv[e] = expf(qv[e] - mx); sm += qv[e]; }
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        if (ok) {
+            const float inv = scale / sm;
+            f32x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = qv[e] * inv; c[e] = qv[4 + e] * inv; }
+            *reinterpret_cast<f32x4*>(Qs + i * LP + part * 8) = a;         // row i is touched by its own 4 lanes only
+            *reinterpret_cast<f32x4*>(Qs + i * LP + part * 8 + 4) = c;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int d = 0; d < 32; ++d) {
+                const float qd = Qs[i * LP + d];
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(ctx + d * LP + part * 8);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(ctx + d * LP + part * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o0[e] += c0[e] * qd; o1[e] += c1[e] * qd; }
+            }
+            float* orow = out + ((int64_t)b * nq + i) * ldo + h * 32 + part * 8;
+            *reinterpret_cast<f32x4*>(orow) = o0;
+            *reinterpret_cast<f32x4*>(orow + 4) = o1;
         }
     }
 }
@@ -362,7 +377,16 @@ extern "C" int dsc_linear_attention_f32(const float* q, int64_t ldq, const float
     if (nk > MAXTOK) return DSC_ERANGE;
     if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(out) ||
         (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DSC_EALIGN;
-    hipLaunchKernelGGL(linear_attention_kernel, dim3(scenes * DSC_HEADS), dim3(128), 0,
+    if (nq > MAXTOK) return DSC_ERANGE;
+    const size_t lds = sizeof(float) * ((size_t)(2 * nk + nq) * LP + 32 * LP);      // <= 74 KB at 160 tokens
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_attention_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(linear_attention_kernel, dim3(scenes * DSC_HEADS), dim3(256), lds,
                        static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, nq, nk, scale);
     DSC_LAUNCH_CHECK();
     return 0;
