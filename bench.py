@@ -145,6 +145,7 @@ def roofline_dominant_kernel(plan, B, N):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / (reps * len(sel))
+    B = plan.B                      # the graph sampler runs the batch as independent half-batch chains
     flops = 2.0 * B * N * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512)" % (B * N),

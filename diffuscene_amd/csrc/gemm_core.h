@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     constexpr int XF = (XTOT + T - 1) / T;
     constexpr int WF = (WTOT + T - 1) / T;
     constexpr int STAGE = (BM + BN) * LDT;
+    constexpr bool XFULL = (XTOT % T) == 0, WFULL = (WTOT % T) == 0;
 
     constexpr int EPI = (BN / 32) * BM + 512 + NW * 32 * 36;      // epilogue scratch: GroupNorm partials + per-wave patches
     constexpr int SMEM = ((DB ? 2 : 1) * STAGE > EPI) ? (DB ? 2 : 1) * STAGE : EPI;
@@ -100,18 +101,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         else           { ab = a2; lda = p.lda2; kk = k0 - p.k1; }
 #pragma unroll
         for (int i = 0; i < XF; ++i) {
+            // branch-free: out-of-range rows read row 0 of the tile (always valid); they are zeroed when staged, so the
+            // wait for the load sits at the ds_write one tile later, not here
             const int f = tid + T * i;
             const int r = f / KQ, kq = f % KQ;
-            if (f < XTOT && r < rows_here) xr[i] = *reinterpret_cast<const f32x4*>(ab + (row0 + r) * lda + kk + kq * 4);
-            else                           xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = (XFULL || f < XTOT) && r < rows_here;
+            xr[i] = *reinterpret_cast<const f32x4*>(ab + (row0 + (ok ? r : 0)) * lda + kk + kq * 4);
         }
 #pragma unroll
         for (int i = 0; i < WF; ++i) {
             const int f = tid + T * i;
             const int r = f / KQ, kq = f % KQ;
             const int c = col0 + r;
-            if (f < WTOT && c < p.n) wr[i] = *reinterpret_cast<const f32x4*>(w + (int64_t)c * p.ldw + k0 + kq * 4);
-            else                     wr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = (WFULL || f < WTOT) && c < p.n;
+            wr[i] = *reinterpret_cast<const f32x4*>(w + (int64_t)(ok ? c : col0) * p.ldw + k0 + kq * 4);
         }
     };
     auto store_tile = [&](float* stage) {
@@ -121,18 +124,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         for (int i = 0; i < XF; ++i) {
             const int f = tid + T * i;
             const int r = f / KQ, kq = f % KQ;
-            f32x4 v = xr[i];
-            if (p.act_in == DSC_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dsc_silu(v[e]);
-            }
-            if (f < XTOT) *reinterpret_cast<f32x4*>(Xs + r * LDT + kq * 4) = v;
+            const f32x4 v = (r < rows_here) ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (XFULL || f < XTOT) *reinterpret_cast<f32x4*>(Xs + r * LDT + kq * 4) = v;
         }
 #pragma unroll
         for (int i = 0; i < WF; ++i) {
             const int f = tid + T * i;
             const int r = f / KQ, kq = f % KQ;
-            if (f < WTOT) *reinterpret_cast<f32x4*>(Ws + r * LDT + kq * 4) = wr[i];
+            const f32x4 v = (col0 + r < p.n) ? wr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (WFULL || f < WTOT) *reinterpret_cast<f32x4*>(Ws + r * LDT + kq * 4) = v;
         }
     };
     auto compute_tile = [&](const float* stage) {

@@ -68,27 +68,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
         for (int q = 0; q < 4; ++q) {
             const int f = tid + 256 * q;
             const int r = f >> 5, c4 = (f & 31) * 4;
-            const long m = m0 + r;
-            if (m < m_end && ic + c4 < kseg) ar[q] = *reinterpret_cast<const f32x4*>(ab + m * lda + ic + c4);
-            else                             ar[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && j0 + c4 < p.n)  br[q] = *reinterpret_cast<const f32x4*>(p.dy + m * p.ldd + j0 + c4);
-            else                             br[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // branch-free: out-of-range elements read a valid address and are zeroed when staged one tile later
+            const long m = (m0 + r < m_end) ? m0 + r : m_begin;
+            ar[q] = *reinterpret_cast<const f32x4*>(ab + m * lda + ic + ((ic + c4 < kseg) ? c4 : 0));
+            br[q] = *reinterpret_cast<const f32x4*>(p.dy + m * p.ldd + j0 + ((j0 + c4 < p.n) ? c4 : 0));
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](long m0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int f = tid + 256 * q;
             const int r = f >> 5, c4 = (f & 31) * 4;
-            *reinterpret_cast<f32x4*>(As + r * TN_LD + c4) = ar[q];
-            *reinterpret_cast<f32x4*>(Bs + r * TN_LD + c4) = br[q];
+            const bool mok = m0 + r < m_end;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(As + r * TN_LD + c4) = (mok && ic + c4 < kseg) ? ar[q] : z;
+            *reinterpret_cast<f32x4*>(Bs + r * TN_LD + c4) = (mok && j0 + c4 < p.n) ? br[q] : z;
         }
     };
 
     if (m_begin < m_end) {
         load_tile(m_begin);
         for (long m0 = m_begin; m0 < m_end; m0 += TN_BK) {
-            store_tile();
+            store_tile(m0);
             __syncthreads();
             if (m0 + TN_BK < m_end) load_tile(m0 + TN_BK);
             if (do_bias) {

@@ -197,8 +197,10 @@ class Plan:
             t2 = self.gemm(t1, net.time_mlp[3].weight, pool.get(B, 4 * D), net.time_mlp[3].bias, act_out=ACT_SILU)
             self.ss_t = self.gemm(t2, e.t_pack_w, pool.get(B, e.t_pack_w.shape[0]), e.t_pack_b)
         if self.ctx_in is not None:
-            self.ss_c = self.gemm(self.ctx_in, e.c_pack_w, pool.get(self.ctx_in.shape[0], e.c_pack_w.shape[0]),
-                                  e.c_pack_b, act_in=ACT_SILU)
+            cact = pool.get(self.ctx_in.shape[0], self.ctx_in.shape[1])       # SiLU of ResnetBlock.mlp (:181-184), once
+            self.call("dsc_activation_f32", self.ctx_in.data_ptr(), cact.data_ptr(), self.ctx_in.numel(), ACT_SILU,
+                      keep=(cact,))
+            self.ss_c = self.gemm(cact, e.c_pack_w, pool.get(self.ctx_in.shape[0], e.c_pack_w.shape[0]), e.c_pack_b)
         else:
             self.ss_c = None
         # ---- input embedding ------------------------------------------------------------------------
@@ -388,8 +390,8 @@ class DenoiserEngine:
             self._ss_table_sig = self.sig
         return self._ss_table
 
-    def plan_for(self, B, N, ctx_mode, ctx_dim, L, text_dim, time_table=False):
-        key = (B, N, ctx_mode, ctx_dim, L, text_dim, time_table)
+    def plan_for(self, B, N, ctx_mode, ctx_dim, L, text_dim, time_table=False, slot=0):
+        key = (B, N, ctx_mode, ctx_dim, L, text_dim, time_table) + ((slot,) if slot else ())
         p = self.plans.get(key)
         if p is None:
             if N > _lib.MAX_TOKENS_PER_SCENE:
@@ -400,7 +402,7 @@ class DenoiserEngine:
         return p
 
     @torch.no_grad()
-    def prepare(self, B, N, context, context_cross, refresh=True, time_table=False):
+    def prepare(self, B, N, context, context_cross, refresh=True, time_table=False, slot=0):
         """Select / build the plan for this signature and upload the step-invariant conditioning.
         time_table=True (reverse loops: integer timesteps below the table size) replaces the time MLP by a table."""
         if refresh:
@@ -416,7 +418,7 @@ class DenoiserEngine:
         L = text_dim = 0
         if context_cross is not None and self.net.text_condition:
             L, text_dim = context_cross.shape[1], context_cross.shape[2]
-        p = self.plan_for(B, N, ctx_mode, ctx_dim, L, text_dim, time_table)
+        p = self.plan_for(B, N, ctx_mode, ctx_dim, L, text_dim, time_table, slot)
         if ctx_mode != SS_NONE:
             p.ctx_in.copy_(context[0] if ctx_mode == SS_PER_SLOT else context.reshape(B * N, ctx_dim))
         if L:

@@ -46,7 +46,7 @@ typedef void* dsc_stream_t; /* hipStream_t */
 int dsc_version(void);
 
 /* ---------------------------------------------------------------------------------------------
- * fp32 MFMA GEMM with fused epilogues:  Y = epilogue( act_in([A1 | A2]) . W^T + bias )
+ * fp32 MFMA GEMM with fused epilogues:  Y = epilogue( [A1 | A2] . W^T + bias )
  *
  * Replaces every 1x1 nn.Conv1d / nn.Linear on the path (denoise_net.py:163,183,188,214,217,244,
  * 245,397,419-421,440,459,487-503) including the torch.cat of skip connections (:562,:566,:573),
@@ -62,7 +62,7 @@ typedef struct dsc_gemm_args {
     const float* residual; int64_t ldr;          /* added after act_out, or NULL */
     float* y; int64_t ldy;
     int32_t m, n;
-    int32_t act_in;                              /* applied to A while staging (SiLU of ResnetBlock.mlp, :181-184) */
+    int32_t act_in;                              /* reserved, must be DSC_ACT_NONE (apply dsc_activation_f32 to A first) */
     int32_t act_out;
     int32_t batch; int64_t sa1, sa2, sw, sbias, sres, sy;
     /* ---- GroupNorm epilogue (dsc_gemm_gn_silu_f32 only) ---- */

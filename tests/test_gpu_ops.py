@@ -47,7 +47,7 @@ def test_gemm_transpose_detecting_identity():
     assert rel(y, a.double() @ w.double().T) < 1e-6
 
 
-@pytest.mark.parametrize("act_in,act_out", [(0, 1), (2, 0), (0, 2)])
+@pytest.mark.parametrize("act_in,act_out", [(0, 1), (0, 0), (0, 2)])
 def test_gemm_epilogues_two_segments_residual(act_in, act_out):
     from diffuscene_amd import ops
     m, n = 200, 512
