@@ -28,6 +28,7 @@ struct TnArgs {
     float* out; long ldo;                     // [n][k1+k2] (or slab s at out + s*slab)
     float* bias_out;                          // optional: column sums of dy (bias gradient), [n] (or slab s)
     long slab;                                // elements between split slabs (0 when splits == 1)
+    long bias_slab;                           // elements between bias slabs
     int m, n, kvalid;                         // kvalid: columns >= kvalid are not stored (padded small-K inputs)
     int chunk;                                // tokens per split (multiple of 32)
     int ktiles;                               // number of 128-wide k tiles
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
         }
     }
     float* out = p.out + (long)split * p.slab;
-    if (do_bias && j0 + tid < p.n) p.bias_out[(long)split * p.slab + j0 + tid] = bsum;
+    if (do_bias && j0 + tid < p.n) p.bias_out[(long)split * p.bias_slab + j0 + tid] = bsum;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int j = j0 + (wj * 2 + b) * 32 + l31;          // output row (n)
@@ -369,151 +370,211 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // =====================================================================================================
-// linear attention backward, block = (scene, head), dynamic LDS: Ks, Vs, DK [nk][33]; Qs, DO [nq][33]; ctx, dctx [32][33]
+// linear attention backward, 256-thread block = (scene, head).  Dynamic LDS (rows padded to 36 floats, float4 access):
+//   Ks (softmaxed k), Vs, DK [nk][36]; Qs (scale * softmax q), DO [nq][36]; ctx, dctx [32][36]; cvec [32]
+//   phase 1  k softmax over tokens (8 lanes / channel), q softmax over channels (4 lanes / token)
+//   phase 2  ctx[d][e] = sum_j ks[j][d] v[j][e],  dctx[d][e] = sum_i qs[i][d] dout[i][e]          (4 outputs / thread)
+//   phase 3  dq  (4 lanes / query token),  phase 4  dks, dv (4 lanes / key token),  phase 5  dk = ks * (dks - <dks, ks>)
 // =====================================================================================================
-constexpr int HP = 33;
+constexpr int HP = 33;      // softmax-attention backward below
+constexpr int LP = 36;
 
-__global__ __launch_bounds__(128) void linear_attention_bwd_kernel(
+__global__ __launch_bounds__(256) void linear_attention_bwd_kernel(
         const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk, const float* __restrict__ v, long ldv,
         const float* __restrict__ dout, long ldo, float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
         float* __restrict__ dv, long lddv, int nq, int nk, float scale) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Ks = lds;
-    float* Vs = Ks + nk * HP;
-    float* DK = Vs + nk * HP;
-    float* Qs = DK + nk * HP;
-    float* DO = Qs + nq * HP;
-    float* ctx = DO + nq * HP;
-    float* dctx = ctx + 32 * HP;
-    float* cvec = dctx + 32 * HP;       // [32] per-channel scratch
+    float* Vs = Ks + nk * LP;
+    float* DK = Vs + nk * LP;
+    float* Qs = DK + nk * LP;
+    float* DO = Qs + nq * LP;
+    float* ctx = DO + nq * LP;
+    float* dctx = ctx + 32 * LP;
+    float* cvec = dctx + 32 * LP;
     const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
     const int tid = threadIdx.x;
-    const float* kb = k + (long)b * nk * ldk + h * 32;
-    const float* vb = v + (long)b * nk * ldv + h * 32;
-    for (int f = tid; f < nk * 8; f += 128) {
+    for (int f = tid; f < nk * 8; f += 256) {
         const int j = f >> 3, c4 = (f & 7) * 4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (long)j * ldk + c4);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (long)j * ldv + c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { Ks[j * HP + c4 + e] = kv[e]; Vs[j * HP + c4 + e] = vv[e]; }
+        const long row = (long)b * nk + j;
+        *reinterpret_cast<f32x4*>(Ks + j * LP + c4) = *reinterpret_cast<const f32x4*>(k + row * ldk + h * 32 + c4);
+        *reinterpret_cast<f32x4*>(Vs + j * LP + c4) = *reinterpret_cast<const f32x4*>(v + row * ldv + h * 32 + c4);
+    }
+    for (int f = tid; f < nq * 8; f += 256) {
+        const int i = f >> 3, c4 = (f & 7) * 4;
+        const long row = (long)b * nq + i;
+        *reinterpret_cast<f32x4*>(Qs + i * LP + c4) = *reinterpret_cast<const f32x4*>(q + row * ldq + h * 32 + c4);
+        *reinterpret_cast<f32x4*>(DO + i * LP + c4) = *reinterpret_cast<const f32x4*>(dout + row * ldo + h * 32 + c4);
     }
     __syncthreads();
-    {   // ks = softmax over tokens (normalised in place)
-        const int d = tid >> 2, part = tid & 3;
+    {   // phase 1a: ks = softmax over tokens (normalised in place)
+        const int d = tid >> 3, part = tid & 7;
         float mx = -INFINITY;
-        for (int j = part; j < nk; j += 4) mx = fmaxf(mx, Ks[j * HP + d]);
+        for (int j = part; j < nk; j += 8) mx = fmaxf(mx, Ks[j * LP + d]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        float sm = 0.f;
+        for (int j = part; j < nk; j += 8) { const float e = expf(Ks[j * LP + d] - mx); Ks[j * LP + d] = e; sm += e; }
+        sm += __shfl_xor(sm, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sm += __shfl_xor(sm, 4, 64);
+        const float inv = 1.0f / sm;
+        for (int j = part; j < nk; j += 8) Ks[j * LP + d] *= inv;
+    }
+    // phase 1b: qs = scale * softmax over channels, 4 lanes per token (each lane touches only its own 8 channels)
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        const int i = i0 + (tid >> 2), part = tid & 3;
+        const bool ok = i < nq;
+        float qv[8];
+        float mx = -INFINITY;
+        if (ok) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Qs + i * LP + part * 8);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(Qs + i * LP + part * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qv[e] = a[e]; qv[4 + e] = c[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, qv[e]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
         float sm = 0.f;
-        for (int j = part; j < nk; j += 4) { const float e = expf(Ks[j * HP + d] - mx); Ks[j * HP + d] = e; sm += e; }
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qv[e] = expf(qv[e] - mx); sm += qv[e]; }
+        }
         sm += __shfl_xor(sm, 1, 64);
         sm += __shfl_xor(sm, 2, 64);
-        const float inv = 1.0f / sm;
-        for (int j = part; j < nk; j += 4) Ks[j * HP + d] *= inv;
-    }
-    // qs = softmax over channels * scale; keep the probabilities' row data in Qs (scaled) and load dout
-    for (int i = tid; i < nq; i += 128) {
-        const float* qr = q + ((long)b * nq + i) * ldq + h * 32;
-        const float* dr = dout + ((long)b * nq + i) * ldo + h * 32;
-        float qv[32];
+        if (ok) {
+            const float inv = scale / sm;
+            f32x4 a, c;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(qr + c * 4);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dr + c * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qv[c * 4 + e] = t4[e]; DO[i * HP + c * 4 + e] = d4[e]; }
+            for (int e = 0; e < 4; ++e) { a[e] = qv[e] * inv; c[e] = qv[4 + e] * inv; }
+            *reinterpret_cast<f32x4*>(Qs + i * LP + part * 8) = a;
+            *reinterpret_cast<f32x4*>(Qs + i * LP + part * 8 + 4) = c;
         }
-        float mx = qv[0];
-#pragma unroll
-        for (int d = 1; d < 32; ++d) mx = fmaxf(mx, qv[d]);
-        float sm = 0.f;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) { qv[d] = expf(qv[d] - mx); sm += qv[d]; }
-        const float inv = 1.0f / sm;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) Qs[i * HP + d] = qv[d] * inv * scale;
     }
     __syncthreads();
-    {   // ctx[d][e] = sum_j ks[j][d] v[j][e];  dctx[d][e] = sum_i qs[i][d] dout[i][e]
-        const int d = tid >> 2, e0 = (tid & 3) * 8;
-        float a[8], g[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = 0.f; g[e] = 0.f; }
+    {   // phase 2: thread -> (d, 4 consecutive e) of ctx and dctx
+        const int d = tid >> 3, e0 = (tid & 7) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < nk; ++j) {
-            const float kd = Ks[j * HP + d];
+            const float kd = Ks[j * LP + d];
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(Vs + j * LP + e0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += kd * Vs[j * HP + e0 + e];
+            for (int e = 0; e < 4; ++e) a[e] += kd * vv[e];
         }
         for (int i = 0; i < nq; ++i) {
-            const float qd = Qs[i * HP + d];
+            const float qd = Qs[i * LP + d];
+            const f32x4 dd = *reinterpret_cast<const f32x4*>(DO + i * LP + e0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] += qd * DO[i * HP + e0 + e];
+            for (int e = 0; e < 4; ++e) g[e] += qd * dd[e];
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ctx[d * HP + e0 + e] = a[e]; dctx[d * HP + e0 + e] = g[e]; }
+        *reinterpret_cast<f32x4*>(ctx + d * LP + e0) = a;
+        *reinterpret_cast<f32x4*>(dctx + d * LP + e0) = g;
     }
     __syncthreads();
-    // dq: dqs[d] = sum_e dout[e] ctx[d][e]; softmax backward with p = qs / scale
-    for (int i = tid; i < nq; i += 128) {
-        float dqs[32];
+    // phase 3: dq.  dqs[d] = sum_e dout[i][e] ctx[d][e];  dq[d] = qs[d] * (dqs[d] - sum_d' dqs[d'] qs[d'] / scale)
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        const int i = i0 + (tid >> 2), part = tid & 3;
+        const bool ok = i < nq;
+        float dqs[8];
         float dot = 0.f;
+        if (ok) {
+            float dov[32];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            float s = 0.f;
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(DO + i * LP + c * 4);
 #pragma unroll
-            for (int e = 0; e < 32; ++e) s += DO[i * HP + e] * ctx[d * HP + e];
-            dqs[d] = s;
-            dot += s * Qs[i * HP + d];          // sum_d dqs[d] * (scale * p[d])
+                for (int e = 0; e < 4; ++e) dov[c * 4 + e] = t4[e];
+            }
+#pragma unroll
+            for (int dd = 0; dd < 8; ++dd) {
+                const int d = part * 8 + dd;
+                float sdd = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(ctx + d * LP + c * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sdd += dov[c * 4 + e] * t4[e];
+                }
+                dqs[dd] = sdd;
+                dot += sdd * Qs[i * LP + d];
+            }
         }
-        float* o = dq + ((long)b * nq + i) * lddq + h * 32;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            f32x4 t4;
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        if (ok) {
+            const float corr = dot / scale;
+            f32x4 a, c;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int d = c * 4 + e;
-                t4[e] = Qs[i * HP + d] * (dqs[d] - dot / scale);   // p*scale*(dqs - sum_d' dqs p), Qs = p*scale
+                a[e] = Qs[i * LP + part * 8 + e] * (dqs[e] - corr);
+                c[e] = Qs[i * LP + part * 8 + 4 + e] * (dqs[4 + e] - corr);
             }
-            *reinterpret_cast<f32x4*>(o + c * 4) = t4;
+            float* o = dq + ((long)b * nq + i) * lddq + h * 32 + part * 8;
+            *reinterpret_cast<f32x4*>(o) = a;
+            *reinterpret_cast<f32x4*>(o + 4) = c;
         }
     }
-    // dks / dv per key token
-    for (int j = tid; j < nk; j += 128) {
-        float dvv[32];
+    // phase 4: per key token (4 lanes): dks for its 8 channels, dv for its 8 outputs
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+        const int j = j0 + (tid >> 2), part = tid & 3;
+        if (j < nk) {
+            float vv[32];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) dvv[e] = 0.f;
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(Vs + j * LP + c * 4);
 #pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            const float kd = Ks[j * HP + d];
-            float s = 0.f;
+                for (int e = 0; e < 4; ++e) vv[c * 4 + e] = t4[e];
+            }
+            f32x4 k0, k1;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) { s += dctx[d * HP + e] * Vs[j * HP + e]; dvv[e] += kd * dctx[d * HP + e]; }
-            DK[j * HP + d] = s;
-        }
-        float* o = dv + ((long)b * nk + j) * lddv + h * 32;
+            for (int dd = 0; dd < 8; ++dd) {
+                const int d = part * 8 + dd;
+                float sdd = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            f32x4 t4;
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(dctx + d * LP + c * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t4[e] = dvv[c * 4 + e];
-            *reinterpret_cast<f32x4*>(o + c * 4) = t4;
+                    for (int e = 0; e < 4; ++e) sdd += vv[c * 4 + e] * t4[e];
+                }
+                if (dd < 4) k0[dd] = sdd; else k1[dd - 4] = sdd;
+            }
+            *reinterpret_cast<f32x4*>(DK + j * LP + part * 8) = k0;
+            *reinterpret_cast<f32x4*>(DK + j * LP + part * 8 + 4) = k1;
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int d = 0; d < 32; ++d) {
+                const float kd = Ks[j * LP + d];
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(dctx + d * LP + part * 8);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(dctx + d * LP + part * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o0[e] += kd * c0[e]; o1[e] += kd * c1[e]; }
+            }
+            float* o = dv + ((long)b * nk + j) * lddv + h * 32 + part * 8;
+            *reinterpret_cast<f32x4*>(o) = o0;
+            *reinterpret_cast<f32x4*>(o + 4) = o1;
         }
     }
     __syncthreads();
-    {   // softmax-over-tokens backward: dk[j][d] = ks[j][d] * (dks[j][d] - sum_j' dks[j'][d] ks[j'][d])
-        const int d = tid >> 2, part = tid & 3;
-        float s = 0.f;
-        for (int j = part; j < nk; j += 4) s += DK[j * HP + d] * Ks[j * HP + d];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (part == 0) cvec[d] = s;
+    {   // phase 5a: per channel <dks, ks> over the tokens
+        const int d = tid >> 3, part = tid & 7;
+        float sdd = 0.f;
+        for (int j = part; j < nk; j += 8) sdd += DK[j * LP + d] * Ks[j * LP + d];
+        sdd += __shfl_xor(sdd, 1, 64);
+        sdd += __shfl_xor(sdd, 2, 64);
+        sdd += __shfl_xor(sdd, 4, 64);
+        if (part == 0) cvec[d] = sdd;
     }
     __syncthreads();
-    for (int f = tid; f < nk * 8; f += 128) {
+    for (int f = tid; f < nk * 8; f += 256) {
         const int j = f >> 3, c4 = (f & 7) * 4;
+        const f32x4 ks4 = *reinterpret_cast<const f32x4*>(Ks + j * LP + c4);
+        const f32x4 dk4 = *reinterpret_cast<const f32x4*>(DK + j * LP + c4);
         f32x4 t4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t4[e] = Ks[j * HP + c4 + e] * (DK[j * HP + c4 + e] - cvec[c4 + e]);
+        for (int e = 0; e < 4; ++e) t4[e] = ks4[e] * (dk4[e] - cvec[c4 + e]);
         *reinterpret_cast<f32x4*>(dk + ((long)b * nk + j) * lddk + h * 32 + c4) = t4;
     }
 }
@@ -681,26 +742,28 @@ extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const 
     const int ktiles = (K + 127) / 128, ntiles = (n + 127) / 128;
     int splits, chunk;
     tn_split(m, n, K, &splits, &chunk);
-    const long wslab = (long)n * ldo;                                  // weight-gradient part of a slab
-    const long slab = wslab + n;                                       // + bias-gradient row
+    const long wslab = (long)n * ldo;                                  // one weight-gradient slab
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TnArgs p{a1, (long)lda1, k1, a2, (long)lda2, k2, dy, (long)ldd, out, (long)ldo, dbias, 0, m, n, kvalid, chunk, ktiles};
+    TnArgs p{a1, (long)lda1, k1, a2, (long)lda2, k2, dy, (long)ldd, out, (long)ldo, dbias, 0, 0, m, n, kvalid, chunk, ktiles};
+    float* bias_ws = nullptr;
     if (splits > 1) {
-        if (!workspace || workspace_floats < slab * splits) return DSC_EINVAL;
+        if (!workspace || workspace_floats < (wslab + n) * splits) return DSC_EINVAL;
         if (ldo != kvalid) return DSC_EINVAL;                          // slab reduction assumes a dense [n][kvalid] output
+        bias_ws = workspace + wslab * splits;                          // compact [splits][n] area behind the weight slabs
         p.out = workspace;
-        p.bias_out = dbias ? workspace + wslab : nullptr;
-        p.slab = slab;
+        p.bias_out = dbias ? bias_ws : nullptr;
+        p.slab = wslab;
+        p.bias_slab = n;
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(ktiles * ntiles, splits), dim3(256), 0, s, p);
     DSC_LAUNCH_CHECK();
     if (splits > 1) {
         long blocks = (wslab + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, slab, splits, out, wslab);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, wslab, splits, out, wslab);
         DSC_LAUNCH_CHECK();
         if (dbias) {
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace + wslab, slab, splits,
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, bias_ws, (long)n, splits,
                                dbias, (long)n);
             DSC_LAUNCH_CHECK();
         }
@@ -788,7 +851,7 @@ extern "C" int dsc_linear_attention_bwd_f32(const float* q, int64_t ldq, const f
     if ((ldq | ldk | ldv | ldo | lddq | lddk | lddv) & 3) return DSC_EALIGN;
     if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(dout) || !dsc_aligned16(dq) ||
         !dsc_aligned16(dk) || !dsc_aligned16(dv)) return DSC_EALIGN;
-    const size_t lds = sizeof(float) * ((size_t)(3 * nk + 2 * nq) * HP + 2 * 32 * HP + 32);
+    const size_t lds = sizeof(float) * ((size_t)(3 * nk + 2 * nq) * LP + 2 * 32 * LP + 32);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_attention_bwd_kernel),
@@ -796,7 +859,7 @@ extern "C" int dsc_linear_attention_bwd_f32(const float* q, int64_t ldq, const f
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(linear_attention_bwd_kernel, dim3(scenes * DSC_HEADS), dim3(128), lds,
+    hipLaunchKernelGGL(linear_attention_bwd_kernel, dim3(scenes * DSC_HEADS), dim3(256), lds,
                        static_cast<hipStream_t>(stream), q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo,
                        dq, (long)lddq, dk, (long)lddk, dv, (long)lddv, nq, nk, scale);
     DSC_LAUNCH_CHECK();
