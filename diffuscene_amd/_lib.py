@@ -107,6 +107,10 @@ def load():
         raise HipLibraryMissing(
             "%s not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "diffuscene_amd has no CPU or PyTorch fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels carry their own libamdhip64; it must be in the process before our library is dlopen'ed,
+    # otherwise our DT_NEEDED resolves to /opt/rocm's copy and the process ends up with two HIP runtimes (kernels
+    # registered in one, streams created by the other -> hipErrorNoDevice on the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -353,6 +353,7 @@ extern "C" int dsc_weight_standardize_f32(const dsc_ws_item* items, int32_t coun
         b.it[i] = items[i];
         if (items[i].rows > maxrows) maxrows = items[i].rows;
     }
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(ws_kernel, dim3(maxrows, count), dim3(256), 0, static_cast<hipStream_t>(stream), b, eps);
     DSC_LAUNCH_CHECK();
     return 0;
@@ -364,6 +365,7 @@ extern "C" int dsc_layernorm_f32(const float* x, int64_t ldx, const float* g, co
     if (d != 512) return DSC_ERANGE;
     if (!dsc_aligned16(x) || !dsc_aligned16(g) || !dsc_aligned16(y) || (ldx & 3) || (ldy & 3)) return DSC_EALIGN;
     if (residual && (!dsc_aligned16(residual) || (ldr & 3))) return DSC_EALIGN;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(layernorm512_kernel, dim3((m + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x, ldx, g, residual, ldr, y, ldy, m, eps);
     DSC_LAUNCH_CHECK();
@@ -386,6 +388,7 @@ extern "C" int dsc_linear_attention_f32(const float* q, int64_t ldq, const float
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(linear_attention_kernel, dim3(scenes * DSC_HEADS), dim3(256), lds,
                        static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, nq, nk, scale);
     DSC_LAUNCH_CHECK();
@@ -399,6 +402,7 @@ extern "C" int dsc_attention_f32(const float* q, int64_t ldq, const float* k, in
     if (n > MAXTOK) return DSC_ERANGE;
     if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(out) ||
         (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DSC_EALIGN;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(attention_kernel, dim3(scenes * DSC_HEADS), dim3(192), 0,
                        static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, n, scale);
     DSC_LAUNCH_CHECK();
@@ -410,6 +414,7 @@ extern "C" int dsc_linear_smallk_f32(const float* x, int64_t ldx, int32_t k_in, 
                                      int32_t act_out, dsc_stream_t stream) {
     if (!x || !w || !y || m < 1 || n < 1 || k_in < 1) return DSC_EINVAL;
     if (k_in > SK_MAXK) return DSC_ERANGE;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(linear_smallk_kernel, dim3((m + SK_TOK - 1) / SK_TOK), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, k_in, w, ldw, bias, y, ldy, m, n, act_out);
     DSC_LAUNCH_CHECK();
@@ -419,6 +424,7 @@ extern "C" int dsc_linear_smallk_f32(const float* x, int64_t ldx, int32_t k_in, 
 extern "C" int dsc_time_embedding_f32(const int64_t* t, int32_t b, int32_t dim, const float* table, int32_t table_rows,
                                       const float* freq, float* out, dsc_stream_t stream) {
     if (!t || !freq || !out || b < 1 || dim < 2 || (dim & 1)) return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(time_embedding_kernel, dim3(b), dim3(256), 0, static_cast<hipStream_t>(stream),
                        t, b, dim, table, table_rows, freq, out);
     DSC_LAUNCH_CHECK();
@@ -429,6 +435,7 @@ extern "C" int dsc_activation_f32(const float* x, float* y, int64_t count, int32
     if (!x || !y || count < 1) return DSC_EINVAL;
     int64_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(activation_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x, y, count, act);
     DSC_LAUNCH_CHECK();

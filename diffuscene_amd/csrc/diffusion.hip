@@ -82,6 +82,7 @@ extern "C" int dsc_q_sample_f32(const float* x0, const float* noise, const int64
                                 const float* sqrt_1mac, float* x_t, float* v_out, int32_t b, int64_t inner,
                                 dsc_stream_t stream) {
     if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t || b < 1 || inner < 1) return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(q_sample_kernel, dim3(grid_x(inner), b), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x0, noise, t, sqrt_ac, sqrt_1mac, x_t, v_out, inner);
     DSC_LAUNCH_CHECK();
@@ -95,6 +96,7 @@ extern "C" int dsc_p_sample_f32(const float* x_t, const float* model_out, const 
     if (!x_t || !model_out || !noise || !t || !coef1 || !coef2 || !sigma || !out || b < 1 || inner < 1) return DSC_EINVAL;
     if (mean_type < DSC_MEAN_EPS || mean_type > DSC_MEAN_V) return DSC_EINVAL;
     if (mean_type != DSC_MEAN_X0 && (!ca || !cb)) return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(p_sample_kernel, dim3(grid_x(inner), b), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x_t, model_out, noise, t, ca, cb, coef1, coef2, sigma, out, x0_out, mean_type, clip, inner);
     DSC_LAUNCH_CHECK();
@@ -103,6 +105,7 @@ extern "C" int dsc_p_sample_f32(const float* x_t, const float* model_out, const 
 
 extern "C" int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t stream) {
     if (!t || count < 1) return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(add_scalar_i64_kernel, dim3((count + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(stream), t, count, delta);
     DSC_LAUNCH_CHECK();
@@ -114,6 +117,7 @@ extern "C" int dsc_complete_overwrite_f32(float* x, const float* partial, const 
                                           int32_t p, int32_t c, dsc_stream_t stream) {
     if (!x || !partial || !noise || !t || !sqrt_ac || !sqrt_1mac || b < 1 || n < 1 || p < 1 || p > n || c < 1)
         return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(complete_overwrite_kernel, dim3(grid_x((int64_t)p * c), b), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, partial, noise, t, sqrt_ac, sqrt_1mac, n, p, c);
     DSC_LAUNCH_CHECK();

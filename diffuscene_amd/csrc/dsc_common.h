@@ -9,6 +9,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DSC_WAVE 64
 
+// hipGetLastError() is per-thread and sticky: another library (PyTorch probing devices while it initialises) can leave
+// an unrelated error behind.  Flush it before our launch so DSC_LAUNCH_CHECK reports only this launch.
+#define DSC_CLEAR_STALE_ERROR() ((void)hipGetLastError())
+
 #define DSC_LAUNCH_CHECK()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

@@ -26,6 +26,7 @@ int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     const int ncb = (a->n + BN - 1) / BN;
     dim3 grid((unsigned)(nrb * ncb), (unsigned)a->batch);
     // XCD-aware block order: the column blocks sharing a token tile run on one XCD and hit its L2
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BKT, false, 2, true>), grid, dim3(64 * WM * WN), 0, s, *a, ncb);
     DSC_LAUNCH_CHECK();
     return 0;

@@ -755,14 +755,17 @@ extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const 
         p.slab = wslab;
         p.bias_slab = n;
     }
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(ktiles * ntiles, splits), dim3(256), 0, s, p);
     DSC_LAUNCH_CHECK();
     if (splits > 1) {
         long blocks = (wslab + 255) / 256;
         if (blocks > 2048) blocks = 2048;
+        DSC_CLEAR_STALE_ERROR();
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, wslab, splits, out, wslab);
         DSC_LAUNCH_CHECK();
         if (dbias) {
+            DSC_CLEAR_STALE_ERROR();
             hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, bias_ws, (long)n, splits,
                                dbias, (long)n);
             DSC_LAUNCH_CHECK();
@@ -786,13 +789,16 @@ extern "C" int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n,
     splits = (m + chunk - 1) / chunk;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (splits == 1) {
+        DSC_CLEAR_STALE_ERROR();
         hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, 1), dim3(256), 0, s, x, (long)ldx, m, n, chunk, out);
         DSC_LAUNCH_CHECK();
         return 0;
     }
     if (!workspace || workspace_floats < (int64_t)splits * n) return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, splits), dim3(256), 0, s, x, (long)ldx, m, n, chunk, workspace);
     DSC_LAUNCH_CHECK();
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, (long)n, splits, out, (long)n);
     DSC_LAUNCH_CHECK();
     return 0;
@@ -809,6 +815,7 @@ extern "C" int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy,
     GnBwdArgs p{z, (long)ldz, dy, (long)ldy, gamma, beta, ss_mode != DSC_SS_NONE ? scale_shift : nullptr, (long)ld_ss,
                 ss_mode, dz, (long)lddz, dgamma_p, dbeta_p, dbias_p, (long)partial_stride, dss, (long)ld_dss, tokens_per_scene,
                 channels, eps};
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(scenes * 8), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     DSC_LAUNCH_CHECK();
     return 0;
@@ -824,6 +831,7 @@ extern "C" int dsc_weight_standardize_bwd_f32(const dsc_ws_bwd_item* items, int3
         b.it[i] = WsBwdItem{items[i].w, items[i].dw_std, items[i].dw, items[i].rows, items[i].cols};
         if (items[i].rows > maxrows) maxrows = items[i].rows;
     }
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(ws_bwd_kernel, dim3(maxrows, count), dim3(256), 0, static_cast<hipStream_t>(stream), b, eps);
     DSC_LAUNCH_CHECK();
     return 0;
@@ -836,6 +844,7 @@ extern "C" int dsc_layernorm_bwd_f32(const float* x, int64_t ldx, const float* g
     if (d != 512) return DSC_ERANGE;
     if (!dsc_aligned16(x) || !dsc_aligned16(g) || !dsc_aligned16(dy) || !dsc_aligned16(dx) || (ldx & 3) || (ldy & 3) ||
         (lddx & 3)) return DSC_EALIGN;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(partial_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x, (long)ldx, g, dy, (long)ldy, dx, (long)lddx, dg_partial, m, eps);
     DSC_LAUNCH_CHECK();
@@ -859,6 +868,7 @@ extern "C" int dsc_linear_attention_bwd_f32(const float* q, int64_t ldq, const f
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(linear_attention_bwd_kernel, dim3(scenes * DSC_HEADS), dim3(256), lds,
                        static_cast<hipStream_t>(stream), q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo,
                        dq, (long)lddq, dk, (long)lddk, dv, (long)lddv, nq, nk, scale);
@@ -882,6 +892,7 @@ extern "C" int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(scenes * DSC_HEADS), dim3(192), lds, static_cast<hipStream_t>(stream),
                        q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo, dq, (long)lddq, dk, (long)lddk,
                        dv, (long)lddv, n, scale);
@@ -894,6 +905,7 @@ extern "C" int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx
     if (!x || !dy || !dx || count < 1) return DSC_EINVAL;
     long blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy, dx,
                        (long)count, act);
     DSC_LAUNCH_CHECK();
@@ -903,6 +915,7 @@ extern "C" int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx
 extern "C" int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t cols,
                                  dsc_stream_t stream) {
     if (!in || !out || rows < 1 || cols < 1) return DSC_EINVAL;
+    DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
                        static_cast<hipStream_t>(stream), in, (long)ldi, out, (long)ldo, rows, cols);
     DSC_LAUNCH_CHECK();

@@ -49,6 +49,11 @@ extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* s
         VP(15, 5, 1, 1, 8, 16, 2)
         VP(16, 5, 1, 1, 4, 32, 1)
         VP(17, 5, 2, 1, 4, 16, 1)
+        V(18, 1, 1, 2, 2, 32, false, 4, true)
+        V(19, 2, 2, 2, 2, 32, false, 3, true)
+        V(20, 2, 1, 2, 2, 32, false, 4, true)
+        V(21, 3, 1, 1, 4, 32, false, 3, true)
+        V(22, 1, 2, 2, 2, 32, false, 4, true)
     }
     return -1;
 }
@@ -62,6 +67,7 @@ extern "C" const char* tune_name(int variant) {
         "9: 160x128 4w BK64 single + XCD", "10: 160x128 4w BK32 DB (1 blk/CU) + XCD",
         "11: 160x256 8w BK16 DB + XCD", "12: 160x256 4w(5x2) BK16 DB + XCD",
         "13: PIPE 160x128 4w BK16 (2 blk/CU)", "14: PIPE 160x256 8w BK32 (1 blk/CU)", "15: PIPE 160x256 8w BK16",
-        "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD"};
-    return (variant >= 0 && variant < 18) ? names[variant] : nullptr;
+        "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD",
+        "18: 64x64 4w (many small blocks)", "19: 128x128 4w 3 waves/SIMD", "20: 128x64 4w", "21: 96x128 4w", "22: 64x128 4w"};
+    return (variant >= 0 && variant < 23) ? names[variant] : nullptr;
 }

@@ -39,8 +39,10 @@ def main():
         r = torch.randn(M, 512, device=dev)
         for gn in (0, 1):
             ref = None
-            for v in range(18):
+            for v in range(23):
                 y = torch.zeros(M, 512, device=dev)
+                if gn and v >= 18:
+                    continue                     # small tiles cannot hold an 80-token scene
                 if gn:
                     g = ops.make_gemm_args(a, w, y, b, a2, r, gamma=gamma, beta=beta, tokens_per_scene=N,
                                            scale_shift=ss, ss_mode=2)
@@ -108,7 +110,7 @@ def main():
                 print("   %-12s %9.0f [%9.0f .. %9.0f]" % (nm, col.mean(), col.min(), col.max()))
     print("\nfit T = a + b*K (us):")
     for gn in (0, 1):
-        for v in range(18):
+        for v in range(23):
             if (512, gn, v) in res and (1024, gn, v) in res:
                 t1, t2 = res[(512, gn, v)], res[(1024, gn, v)]
                 bb = (t2 - t1) / 512
