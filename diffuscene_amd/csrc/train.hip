@@ -921,3 +921,224 @@ extern "C" int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64
     DSC_LAUNCH_CHECK();
     return 0;
 }
+
+// =====================================================================================================
+// Training loss of reference p_losses (diffusion_ddpm.py:556-652) -- forward AND d(loss)/d(denoise_out) in one kernel.
+// One 256-thread block per scene:
+//   separated MSE terms over the attribute slices, loss_weight[t] scaling, and (loss_iou) the pairwise axis-aligned
+//   3-D IoU regulariser of loss.py:7-102 on the de-normalised, clamped x0 estimate, masked by predicted emptiness.
+// parts[b] = {bbox, trans, size, angle, class, object, objfeat, liou, bbox_iou} of scene b; dout[b] = d losses_weight[b] / d out[b].
+// =====================================================================================================
+namespace {
+
+struct LossArgs {
+    const float* target; const float* out; const float* x_t; const int64_t* t;
+    const float* loss_weight; const float* ca; const float* cb; const float* alphas_cumprod;
+    float* losses; float* parts; float* dout;
+    int n, c, tr, sz, bb, nc, no, nf;
+    int separate, iou, mean_type;
+    float c_lo[3], c_span[3], s_lo[3], s_span[3];
+};
+
+constexpr int LOSS_MAXN = 160;
+
+__device__ __forceinline__ float block_sum_loss(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ddpm_loss_kernel(const LossArgs p) {
+    __shared__ float red[4];
+    __shared__ float lo[LOSS_MAXN][3], hi[LOSS_MAXN][3], valid[LOSS_MAXN], giou[LOSS_MAXN][6];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = p.n, C = p.c;
+    const long base = (long)b * N * C;
+    const int64_t tv = p.t[b];
+    const float lw = p.loss_weight[tv];
+    const int c_trans = p.tr, c_size = p.tr + p.sz, c_bbox = p.bb, c_class = p.bb + p.nc;
+    const int c_obj0 = (p.no == 0) ? c_class - 1 : c_class, c_obj1 = c_class + p.no;
+    // ---- squared-error sums per slice
+    float s_tr = 0.f, s_sz = 0.f, s_an = 0.f, s_cl = 0.f, s_ob = 0.f, s_ft = 0.f, s_all = 0.f;
+    for (int e = tid; e < N * C; e += 256) {
+        const int ch = e % C;
+        const float d = p.target[base + e] - p.out[base + e];
+        const float q = d * d;
+        s_all += q;
+        if (ch < c_trans) s_tr += q;
+        else if (ch < c_size) s_sz += q;
+        else if (ch < c_bbox) s_an += q;
+        else if (ch < c_class) s_cl += q;
+        else if (ch >= c_obj1) s_ft += q;
+        if (ch >= c_obj0 && ch < c_obj1) s_ob += q;
+    }
+    s_tr = block_sum_loss(s_tr, red); s_sz = block_sum_loss(s_sz, red); s_an = block_sum_loss(s_an, red);
+    s_cl = block_sum_loss(s_cl, red); s_ob = block_sum_loss(s_ob, red); s_ft = block_sum_loss(s_ft, red);
+    s_all = block_sum_loss(s_all, red);
+    const float fn = (float)N;
+    const float l_trans = s_tr / (fn * p.tr), l_size = s_sz / (fn * p.sz), l_angle = s_an / (fn * (p.bb - p.tr - p.sz));
+    const float l_bbox = (s_tr + s_sz + s_an) / (fn * p.bb), l_class = s_cl / (fn * p.nc);
+    const float l_obj = s_ob / (fn * (c_obj1 - c_obj0));
+    const float l_feat = p.nf > 0 ? s_ft / (fn * p.nf) : 0.f;
+    float losses;
+    if (p.separate) {
+        losses = l_bbox + l_class;
+        if (p.no > 0) losses += l_obj;
+        if (p.nf > 0) losses += l_feat;
+    } else losses = s_all / (fn * C);
+    float lossw = losses * lw;
+    // ---- IoU regulariser
+    float liou = 0.f, iou_avg = 0.f;
+    const float A = (p.mean_type == DSC_MEAN_X0) ? 0.f : p.ca[tv];
+    const float Bc = (p.mean_type == DSC_MEAN_X0) ? -1.f : p.cb[tv];     // x0 = A * x_t - Bc * out
+    if (p.iou) {
+        const int oc = (p.no > 0) ? c_class : c_class - 1;
+        if (tid < N) {
+            const long row = base + (long)tid * C;
+            float xr[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float raw = A * p.x_t[row + k] - Bc * p.out[row + k];
+                xr[k] = fminf(fmaxf(raw, -1.0f), 1.0f);
+            }
+            const float ob = fminf(fmaxf(A * p.x_t[row + oc] - Bc * p.out[row + oc], -1.0f), 1.0f);
+            valid[tid] = (p.no > 0) ? (ob >= 0.f ? 1.f : 0.f) : (ob <= 0.f ? 1.f : 0.f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float ctr = (xr[k] + 1.0f) * 0.5f * p.c_span[k] + p.c_lo[k];
+                const float siz = (xr[3 + k] + 1.0f) * 0.5f * p.s_span[k] + p.s_lo[k];
+                lo[tid][k] = ctr - siz;
+                hi[tid][k] = ctr + siz;
+            }
+        }
+        __syncthreads();
+        float S = 0.f, cnt = 0.f;
+        float glo[3] = {0.f, 0.f, 0.f}, ghi[3] = {0.f, 0.f, 0.f};
+        if (tid < N && valid[tid] > 0.f) {
+            const int i = tid;
+            float li[3], hi_i[3], ei[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { li[k] = lo[i][k]; hi_i[k] = hi[i][k]; ei[k] = hi_i[k] - li[k]; }
+            const float vi = ei[0] * ei[1] * ei[2];
+            for (int j = 0; j < N; ++j) {
+                if (valid[j] <= 0.f) continue;
+                cnt += 1.0f;
+                float wh[3], ej[3];
+                bool r_is_i[3], l_is_i[3], r_tie[3], l_tie[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float hj = hi[j][k], lj = lo[j][k];
+                    ej[k] = hj - lj;
+                    const float r = fminf(hi_i[k], hj), l = fmaxf(li[k], lj);
+                    r_is_i[k] = hi_i[k] < hj; r_tie[k] = hi_i[k] == hj;
+                    l_is_i[k] = li[k] > lj; l_tie[k] = li[k] == lj;
+                    wh[k] = fmaxf(r - l, 0.f);
+                }
+                const float vj = ej[0] * ej[1] * ej[2];
+                const float o = wh[0] * wh[1] * wh[2];
+                const float uraw = vi + vj - o;
+                const bool ucl = !(uraw > 1e-6f);                 // union clamped to eps
+                const float u = ucl ? 1e-6f : uraw;
+                S += o / u;
+                if (j == i) {
+                    // both arguments are box i: o = u = vi, the quotient is constant unless the union is clamped
+                    if (ucl) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const float dv = ei[(k + 1) % 3] * ei[(k + 2) % 3] / u;
+                            ghi[k] += dv; glo[k] -= dv;
+                        }
+                    }
+                    continue;
+                }
+                // d iou / d box_i with box_j fixed; the (j, i) pair contributes the same amount (symmetry) -> factor 2
+                const float dio = ucl ? 1.0f / u : (u + o) / (u * u);      // d iou / d o   (du/do = -1)
+                const float diu = ucl ? 0.f : -o / (u * u);                // d iou / d vi  (through the union)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float others = wh[(k + 1) % 3] * wh[(k + 2) % 3];
+                    const float pass = (fminf(hi_i[k], hi[j][k]) - fmaxf(li[k], lo[j][k]) >= 0.f) ? 1.f : 0.f;
+                    const float dwh = dio * others * pass;                 // d iou / d wh_k
+                    const float wr = r_tie[k] ? 0.5f : (r_is_i[k] ? 1.f : 0.f);
+                    const float wl = l_tie[k] ? 0.5f : (l_is_i[k] ? 1.f : 0.f);
+                    const float dvi = ei[(k + 1) % 3] * ei[(k + 2) % 3];   // d vi / d e_k
+                    ghi[k] += 2.0f * (dwh * wr + diu * dvi);
+                    glo[k] += 2.0f * (-dwh * wl - diu * dvi);
+                }
+            }
+        }
+        const float Ssum = block_sum_loss(S, red);
+        const float csum = block_sum_loss(cnt, red) + 1e-6f;
+        const float w = p.alphas_cumprod[tv];
+        iou_avg = Ssum / csum;
+        liou = w * 0.1f * Ssum / csum;
+        lossw += liou;
+        if (tid < N) {
+            const float sc = (valid[tid] > 0.f) ? w * 0.1f / csum : 0.f;
+            const long row = base + (long)tid * C;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float dctr = (glo[k] + ghi[k]) * sc, dsiz = (ghi[k] - glo[k]) * sc;
+                const float raw_c = A * p.x_t[row + k] - Bc * p.out[row + k];
+                const float raw_s = A * p.x_t[row + 3 + k] - Bc * p.out[row + 3 + k];
+                const float pc = (raw_c >= -1.0f && raw_c <= 1.0f) ? 1.f : 0.f;
+                const float ps = (raw_s >= -1.0f && raw_s <= 1.0f) ? 1.f : 0.f;
+                giou[tid][k] = dctr * 0.5f * p.c_span[k] * pc * (-Bc);
+                giou[tid][3 + k] = dsiz * 0.5f * p.s_span[k] * ps * (-Bc);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.losses[b] = lossw;
+        float* q = p.parts + (long)b * 9;
+        q[0] = l_bbox; q[1] = l_trans; q[2] = l_size; q[3] = l_angle; q[4] = l_class; q[5] = l_obj; q[6] = l_feat;
+        q[7] = liou; q[8] = iou_avg;
+    }
+    // ---- gradient of losses_weight[b] w.r.t. out[b]
+    const float g_bbox = p.separate ? lw * 2.0f / (fn * p.bb) : lw * 2.0f / (fn * C);
+    const float g_class = p.separate ? lw * 2.0f / (fn * p.nc) : g_bbox;
+    const float g_obj = p.separate ? (p.no > 0 ? lw * 2.0f / (fn * p.no) : 0.f) : g_bbox;
+    const float g_feat = p.separate ? (p.nf > 0 ? lw * 2.0f / (fn * p.nf) : 0.f) : g_bbox;
+    for (int e = tid; e < N * C; e += 256) {
+        const int ch = e % C, i = e / C;
+        const float d = p.out[base + e] - p.target[base + e];
+        float g = (ch < c_bbox) ? g_bbox : (ch < c_class) ? g_class : (ch < c_obj1) ? g_obj : g_feat;
+        g *= d;
+        if (p.iou && ch < 6) g += giou[i][ch];
+        p.dout[base + e] = g;
+    }
+}
+
+}  // namespace
+
+extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const float* x_t, const int64_t* t,
+                                 const float* loss_weight, const float* ca, const float* cb, const float* alphas_cumprod,
+                                 const float* bounds /* host: c_lo[3] c_hi[3] s_lo[3] s_hi[3], may be NULL */,
+                                 float* losses, float* parts, float* dout, int32_t b, int32_t n, int32_t c,
+                                 int32_t translation_dim, int32_t size_dim, int32_t bbox_dim, int32_t class_dim,
+                                 int32_t objectness_dim, int32_t objfeat_dim, int32_t loss_separate, int32_t loss_iou,
+                                 int32_t mean_type, dsc_stream_t stream) {
+    if (!target || !out || !x_t || !t || !loss_weight || !losses || !parts || !dout || b < 1 || n < 1) return DSC_EINVAL;
+    if (n > LOSS_MAXN) return DSC_ERANGE;
+    if (c != bbox_dim + class_dim + objectness_dim + objfeat_dim) return DSC_EINVAL;
+    if (translation_dim != 3 || size_dim != 3) return DSC_ERANGE;
+    if (loss_iou && (!bounds || !alphas_cumprod)) return DSC_EINVAL;
+    if (mean_type != DSC_MEAN_X0 && (!ca || !cb)) return DSC_EINVAL;
+    LossArgs p{};
+    p.target = target; p.out = out; p.x_t = x_t; p.t = t; p.loss_weight = loss_weight; p.ca = ca; p.cb = cb;
+    p.alphas_cumprod = alphas_cumprod; p.losses = losses; p.parts = parts; p.dout = dout;
+    p.n = n; p.c = c; p.tr = translation_dim; p.sz = size_dim; p.bb = bbox_dim; p.nc = class_dim; p.no = objectness_dim;
+    p.nf = objfeat_dim; p.separate = loss_separate; p.iou = loss_iou; p.mean_type = mean_type;
+    if (bounds)
+        for (int k = 0; k < 3; ++k) {
+            p.c_lo[k] = bounds[k]; p.c_span[k] = bounds[3 + k] - bounds[k];
+            p.s_lo[k] = bounds[6 + k]; p.s_span[k] = bounds[9 + k] - bounds[6 + k];
+        }
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(ddpm_loss_kernel, dim3(b), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}

@@ -380,3 +380,21 @@ def activation_bwd(x, dy, act):
     _lib.check(_lib.fn("dsc_activation_bwd_f32")(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), act,
                                                  stream_ptr()), "dsc_activation_bwd_f32")
     return dx
+
+
+def ddpm_loss(target, out, x_t, t, loss_weight, ca, cb, alphas_cumprod, bounds, dims, separate, iou, mean_type):
+    """-> losses_weight [B], parts [B, 9], dout [B, N, C] (d losses_weight[b] / d out[b])"""
+    _c(target, "target"); _c(out, "out"); _c(x_t, "x_t"); _dev(t, "t", torch.int64)
+    B, N, Cc = out.shape
+    losses = torch.empty((B,), device=out.device, dtype=torch.float32)
+    parts = torch.empty((B, 9), device=out.device, dtype=torch.float32)
+    dout = torch.empty_like(out)
+    barr = (C.c_float * 12)(*[float(v) for v in bounds]) if bounds is not None else None
+    _lib.check(_lib.fn("dsc_ddpm_loss_f32")(
+        target.data_ptr(), out.data_ptr(), x_t.data_ptr(), t.data_ptr(), loss_weight.data_ptr(),
+        ca.data_ptr() if ca is not None else None, cb.data_ptr() if cb is not None else None,
+        alphas_cumprod.data_ptr() if alphas_cumprod is not None else None, barr,
+        losses.data_ptr(), parts.data_ptr(), dout.data_ptr(), B, N, Cc, dims["translation_dim"], dims["size_dim"],
+        dims["bbox_dim"], dims["class_dim"], dims["objectness_dim"], dims["objfeat_dim"], 1 if separate else 0,
+        1 if iou else 0, mean_type, stream_ptr()), "dsc_ddpm_loss_f32")
+    return losses, parts, dout

@@ -13,13 +13,44 @@ def unet1d_forward_autograd(net, x, t, context, context_cross):
     return unet1d_train_forward(net, x, t, context, context_cross)
 
 
+class DdpmLossFn(torch.autograd.Function):
+    """losses_weight (B,) and the 9 logged per-scene terms from ONE kernel that also produces d loss / d denoise_out."""
+
+    @staticmethod
+    def forward(ctx, denoise_out, target, data_t, t, diff, tb):
+        from . import ops
+        ca, cb = diff._coeffs(tb)
+        bounds = None
+        if diff.loss_iou:
+            bounds = list(diff._centroids[0]) + list(diff._centroids[1]) + list(diff._sizes[0]) + list(diff._sizes[1])
+        dims = dict(translation_dim=diff.translation_dim, size_dim=diff.size_dim, bbox_dim=diff.bbox_dim,
+                    class_dim=diff.class_dim, objectness_dim=diff.objectness_dim, objfeat_dim=diff.objfeat_dim)
+        losses, parts, dout = ops.ddpm_loss(target.contiguous(), denoise_out.contiguous(), data_t.contiguous(), t,
+                                            tb["loss_weight"], ca, cb, tb["alphas_cumprod"], bounds, dims,
+                                            diff.loss_separate, diff.loss_iou,
+                                            {"eps": ops.MEAN_EPS, "x0": ops.MEAN_X0, "v": ops.MEAN_V}[diff.model_mean_type])
+        ctx.save_for_backward(dout)
+        ctx.mark_non_differentiable(parts)
+        return losses, parts
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_parts):
+        dout, = ctx.saved_tensors
+        return dout * g_losses.reshape(-1, 1, 1), None, None, None, None, None
+
+
+_PART_KEYS = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class', 'loss.object', 'loss.objfeat',
+              'loss.liou', 'loss.bbox_iou')
+
+
 def _mse(target, out, a, b):
     return ((target[:, :, a:b] - out[:, :, a:b]) ** 2).mean(dim=(1, 2))
 
 
-def diffusion_losses(diff, tb, data_start, data_t, target, denoise_out, t):
+def diffusion_losses(diff, tb, data_start, data_t, target, denoise_out, t, fused=True):
     """Separated MSE terms, loss_weight[t] scaling and the 3-D IoU regulariser of reference p_losses
-    (diffusion_ddpm.py:558-652).  Small (B,N,C)/(B,N,N) tensors: device torch ops under autograd."""
+    (diffusion_ddpm.py:558-652).  The shipped attribute layout goes through the fused HIP kernel (DdpmLossFn); the
+    re-arrangement loss and exotic layouts use device torch ops under autograd (also the kernel's test reference)."""
     B = data_start.shape[0]
     tr, sz, bb = diff.translation_dim, diff.size_dim, diff.bbox_dim
     nc, no, nf = diff.class_dim, diff.objectness_dim, diff.objfeat_dim
@@ -36,6 +67,11 @@ def diffusion_losses(diff, tb, data_start, data_t, target, denoise_out, t):
     if data_start.shape[-1] != no + nc + bb + nf:
         print('unimplement point dim is: ', data_start.shape[-1])
         raise NotImplementedError
+    if fused and tr == 3 and sz == 3 and data_start.shape[1] <= 160:
+        # the shipped layout: one fused HIP kernel for all terms and for d loss / d denoise_out
+        losses_weight, parts = DdpmLossFn.apply(denoise_out, target, data_t, t, diff, tb)
+        means = parts.mean(dim=0)
+        return losses_weight, {k: means[i] for i, k in enumerate(_PART_KEYS)}
     loss_trans = _mse(target, denoise_out, 0, tr)
     loss_size = _mse(target, denoise_out, tr, tr + sz)
     loss_angle = _mse(target, denoise_out, tr + sz, bb)

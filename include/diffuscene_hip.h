@@ -204,6 +204,19 @@ int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t l
                           const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk, int64_t lddk,
                           float* dv, int64_t lddv, int32_t scenes, int32_t n, float scale, dsc_stream_t stream);
 
+/* Training loss of p_losses (diffusion_ddpm.py:556-652, loss_type 'mse', full attribute tensor) and its gradient in
+ * one kernel, one block per scene: separated MSE terms x loss_weight[t] + the masked pairwise 3-D IoU regulariser
+ * (loss.py:7-102) on the clamped, de-normalised x0 estimate  x0 = ca[t]*x_t - cb[t]*out  (mean_type v / eps; out itself
+ * for x0).  losses[b] = losses_weight of scene b; parts[b][9] = {bbox, trans, size, angle, class, object, objfeat,
+ * liou, bbox_iou}; dout[b] = d losses[b] / d out[b].  bounds is a HOST array {centroid min[3], max[3], size min[3],
+ * max[3]} (dataset_stats.txt, :137-151), required when loss_iou. */
+int dsc_ddpm_loss_f32(const float* target, const float* out, const float* x_t, const int64_t* t,
+                      const float* loss_weight, const float* ca, const float* cb, const float* alphas_cumprod,
+                      const float* bounds, float* losses, float* parts, float* dout, int32_t b, int32_t n, int32_t c,
+                      int32_t translation_dim, int32_t size_dim, int32_t bbox_dim, int32_t class_dim,
+                      int32_t objectness_dim, int32_t objfeat_dim, int32_t loss_separate, int32_t loss_iou,
+                      int32_t mean_type, dsc_stream_t stream);
+
 /* dx = dy * act'(x) */
 int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx, int64_t count, int32_t act, dsc_stream_t stream);
 

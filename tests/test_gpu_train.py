@@ -189,6 +189,41 @@ def _oracle_grad_norms_fp64(kw, x, t, cond, noise, names, cross=None, iou=True):
     return np.array([float(sd[k].grad.norm()) for k in names]), lw.detach()
 
 
+@pytest.mark.parametrize("mean_type,iou,B,N", [("v", True, 5, 21), ("eps", True, 3, 12), ("x0", True, 2, 80), ("v", False, 4, 12)])
+def test_fused_loss_kernel_matches_torch_definition(tmp_path, mean_type, iou, B, N):
+    """dsc_ddpm_loss_f32 (all loss terms + d loss / d denoise_out in one kernel) vs the torch-op definition of the same
+    loss under autograd (train_graph.diffusion_losses(fused=False)), incl. overlapping boxes and empty slots."""
+    from diffuscene_amd import train_graph as tg
+    from diffuscene_amd.networks.diffusion_ddpm import GaussianDiffusion, get_betas
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    cfg = dict(objectness_dim=0, class_dim=25, angle_dim=2, objfeat_dim=32)
+    d = GaussianDiffusion(cfg, get_betas("linear", 1e-4, 0.02, 1000), "mse", mean_type, "fixedsmall", True, iou,
+                          str(stats) if iou else None)
+    tb = d.tables(dev())
+    x0 = W.synth_scene_batch(B, N, 25, 32, seed=21)
+    x0[:, :, 0:3] *= 0.3                       # crowd the boxes so that many pairs overlap
+    t = torch.tensor([(17 + 233 * i) % 1000 for i in range(B)], dtype=torch.int64)
+    noise = W.synth_noise((B, N, 65), 3, "lossn")
+    tbc = R.schedule_tables(1e-4, 0.02, 1000, mean_type)
+    xt = R.q_sample(tbc, x0, t, noise)
+    target = {"v": R.predict_v(tbc, x0, t, noise), "eps": noise, "x0": x0}[mean_type]
+    out = target + 0.3 * rnd(B, N, 65, seed=22)
+    res = []
+    for fused in (True, False):
+        o = out.to(dev()).requires_grad_(True)
+        lw, scal = tg.diffusion_losses(d, tb, x0.to(dev()), xt.to(dev()), target.to(dev()), o, t.to(dev()), fused=fused)
+        (lw * torch.arange(1, B + 1, device=dev())).sum().backward()
+        res.append((lw.detach(), {k: float(v) for k, v in scal.items()}, o.grad))
+    (lw_f, sc_f, g_f), (lw_t, sc_t, g_t) = res
+    assert rel(lw_f, lw_t) < 2e-5
+    for k in sc_t:
+        assert abs(sc_f[k] - sc_t[k]) <= 2e-5 * max(1.0, abs(sc_t[k])), (k, sc_f[k], sc_t[k])
+    if iou:
+        assert sc_t["loss.bbox_iou"] > 1e-3                      # the IoU term is really exercised
+    assert rel(g_f, g_t) < 5e-5, rel(g_f, g_t)
+
+
 def test_text_conditioned_training_gradients_vs_fp64():
     """config/text (cross-attention on 512-d text tokens): loss and every parameter gradient of the
     HIP path against the fp64 oracle; also gradients w.r.t. the conditioning inputs."""
