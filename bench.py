@@ -148,10 +148,19 @@ def roofline_dominant_kernel(plan, B, N):
     B = plan.B                      # the graph sampler runs the batch as independent half-batch chains
     flops = 2.0 * B * N * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01_gemm_gn_hbm_traffic.json")
+    if os.path.exists(tfile) and B * N == 20480:
+        # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), measured
+        # offline on the same workload -- bench.py cannot run the profiler on itself
+        with open(tfile) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"])
+        traffic_src = "profiles/r01_gemm_gn_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
     return {"bound": "mfma", "kernel": "gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512)" % (B * N),
             "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
-            "launches_per_step": len(steps), "traffic": None}
+            "launches_per_step": len(steps), "algorithmic_flops_per_launch": flops,
+            "traffic": traffic, "traffic_source": traffic_src}
 
 
 def cpu_baseline(args, mode):

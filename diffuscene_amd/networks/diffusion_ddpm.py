@@ -303,10 +303,15 @@ class GaussianDiffusion:
         raise NotImplementedError("ddim_sample_loop is dead code in the reference (diffusion_ddpm.py:419-420)")
 
     def p_sample_loop_complete(self, denoise_fn, shape, device, condition, condition_cross, noise_fn=torch.randn,
-                               clip_denoised=True, keep_running=False, partial_boxes=None):
+                               clip_denoised=True, keep_running=False, partial_boxes=None, graph=None):
         """Scene completion, reference :447-476: every step re-noises the given objects (noise drawn BEFORE the
         model call) and overwrites the first P rows of x_t in place; at t == 0 the clean objects are restored."""
         assert isinstance(shape, (tuple, list))
+        if _use_graph(graph, noise_fn):
+            from ..sampler import graph_sample_loop
+            print('last:', 0, self.num_timesteps, len(self.betas))
+            return graph_sample_loop(self, denoise_fn, tuple(shape), device, condition, condition_cross, clip_denoised,
+                                     self._total_steps(keep_running), noise_fn, partial_boxes=partial_boxes.contiguous())
         tb = self.tables(device)
         img_t = noise_fn(size=shape, dtype=torch.float, device=device).clone()   # overwritten in place below
         partial_boxes = partial_boxes.contiguous()
@@ -326,9 +331,20 @@ class GaussianDiffusion:
         return img_t
 
     def p_sample_loop_arrange(self, denoise_fn, shape, device, condition, condition_cross, noise_fn=torch.randn,
-                              clip_denoised=True, keep_running=False, input_boxes=None):
+                              clip_denoised=True, keep_running=False, input_boxes=None, graph=None):
         """Re-arrangement, reference :478-506: diffuse [translation | angle] only, re-assemble at t == 0."""
         assert isinstance(shape, (tuple, list))
+        if _use_graph(graph, noise_fn):
+            from ..sampler import graph_sample_loop
+            sub = (shape[0], shape[1], self.translation_dim + self.angle_dim)
+            img_t = graph_sample_loop(self, denoise_fn, sub, device, condition, condition_cross, clip_denoised,
+                                      self._total_steps(keep_running), noise_fn)
+            print('last:', 0, self.num_timesteps, len(self.betas))
+            tr, sz, bb = self.translation_dim, self.size_dim, self.bbox_dim
+            img_t = torch.cat([img_t[:, :, 0:tr], input_boxes[:, :, tr:tr + sz], img_t[:, :, tr:],
+                               input_boxes[:, :, bb:]], dim=-1).contiguous()
+            assert img_t.shape == shape
+            return img_t
         img_t = noise_fn(size=(shape[0], shape[1], self.translation_dim + self.angle_dim), dtype=torch.float,
                          device=device)
         for t in reversed(range(0, self._total_steps(keep_running))):
@@ -437,15 +453,15 @@ class DiffusionPoint(nn.Module):
         return self.diffusion.ddim_sample_loop(*args, **kwargs)
 
     def complete_samples(self, shape, device, condition=None, condition_cross=None, noise_fn=torch.randn,
-                         clip_denoised=True, keep_running=False, partial_boxes=None):
+                         clip_denoised=True, keep_running=False, partial_boxes=None, graph=None):
         return self.diffusion.p_sample_loop_complete(self._denoise, shape=shape, device=device, condition=condition,
                                                      condition_cross=condition_cross, noise_fn=noise_fn,
                                                      clip_denoised=clip_denoised, keep_running=keep_running,
-                                                     partial_boxes=partial_boxes)
+                                                     partial_boxes=partial_boxes, graph=graph)
 
     def arrange_samples(self, shape, device, condition=None, condition_cross=None, noise_fn=torch.randn,
-                        clip_denoised=True, keep_running=False, input_boxes=None):
+                        clip_denoised=True, keep_running=False, input_boxes=None, graph=None):
         return self.diffusion.p_sample_loop_arrange(self._denoise, shape=shape, device=device, condition=condition,
                                                     condition_cross=condition_cross, noise_fn=noise_fn,
                                                     clip_denoised=clip_denoised, keep_running=keep_running,
-                                                    input_boxes=input_boxes)
+                                                    input_boxes=input_boxes, graph=graph)

@@ -19,11 +19,18 @@ class NoiseReplay:
     ``buffer[i]`` for the i-th draw.  Usable eagerly and inside the captured graph (parity tests inject the
     reference's noise this way)."""
 
-    def __init__(self, buffer):
-        self.buffer = buffer
+    def __init__(self, buffer, partial_buffer=None):
+        self.buffer = buffer                      # (T+1, B, N, C): x_T, then the p_sample draw of every step
+        self.partial_buffer = partial_buffer      # (T, B, P, C): completion only, the draw that re-noises the given objects
         self.i = 0
+        self.ip = 0
 
     def __call__(self, size=None, dtype=None, device=None):
+        if self.partial_buffer is not None and tuple(size) == tuple(self.partial_buffer.shape[1:]) \
+                and tuple(size) != tuple(self.buffer.shape[1:]):
+            n = self.partial_buffer[self.ip]
+            self.ip += 1
+            return n
         n = self.buffer[self.i]
         self.i += 1
         assert tuple(n.shape) == tuple(size), (tuple(n.shape), tuple(size))
@@ -41,7 +48,8 @@ def _chains_for(B):
 
 
 class _StepGraph:
-    def __init__(self, diff, model, shape, device, condition, condition_cross, clip_denoised, replay=False):
+    def __init__(self, diff, model, shape, device, condition, condition_cross, clip_denoised, replay=False,
+                 partial_shape=None):
         B, N, C = shape
         self.shape = shape
         eng = model.engine(device)
@@ -63,6 +71,11 @@ class _StepGraph:
         self.replay = replay
         self.noise_buf = None                                   # (T+1, B, N, C) when replaying
         self.draw = torch.zeros((1,), device=device, dtype=torch.int64)
+        # scene completion (p_sample_loop_complete, diffusion_ddpm.py:461-466): the given objects are re-noised and
+        # written over the first P rows of x_t at every step, BEFORE the model call
+        self.partial = torch.zeros(partial_shape, device=device) if partial_shape is not None else None
+        self.pnoise_buf = None
+        self.pdraw = torch.zeros((1,), device=device, dtype=torch.int64)
 
         xv = self.x.view(B * N, C)
         self.model_out = torch.empty(shape, device=device, dtype=torch.float32) if nch > 1 else None
@@ -76,6 +89,14 @@ class _StepGraph:
                 self.model_out.view(B * N, C)[i * Bc * N:(i + 1) * Bc * N].copy_(p.out)
 
         def step():
+            if self.partial is not None:
+                if self.replay:
+                    pn = self.pnoise_buf.index_select(0, self.pdraw)[0]
+                    ops.add_scalar_i64(self.pdraw, 1)
+                else:
+                    pn = torch.randn(partial_shape, dtype=torch.float, device=device)
+                ops.complete_overwrite(self.x, self.partial, pn, self.t, tb["sqrt_alphas_cumprod"],
+                                       tb["sqrt_one_minus_alphas_cumprod"])
             cur = torch.cuda.current_stream(device)
             for st in self.side:
                 st.wait_stream(cur)
@@ -100,6 +121,8 @@ class _StepGraph:
         self.t.fill_(1)
         if replay:
             self.noise_buf = torch.zeros((diff.num_timesteps + 1,) + tuple(shape), device=device)
+            if partial_shape is not None:
+                self.pnoise_buf = torch.zeros((diff.num_timesteps,) + tuple(partial_shape), device=device)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
@@ -109,32 +132,38 @@ class _StepGraph:
         with torch.cuda.graph(self.graph):
             step()
 
-    def run(self, x_T, total_steps, noise_buffer=None):
+    def run(self, x_T, total_steps, noise_buffer=None, partial=None, partial_noise=None):
         self.x.copy_(x_T)
         self.t.fill_(total_steps - 1)
+        if self.partial is not None:
+            self.partial.copy_(partial)
         if self.replay:
             self.noise_buf[:noise_buffer.shape[0]].copy_(noise_buffer)
             self.draw.fill_(1)                                  # draw 0 was x_T
+            if self.partial is not None:
+                self.pnoise_buf[:partial_noise.shape[0]].copy_(partial_noise)
+                self.pdraw.fill_(0)
         for _ in range(total_steps):
             self.graph.replay()
         return self.x.clone()
 
 
 def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cross, clip_denoised, total_steps,
-                      noise_fn=torch.randn):
+                      noise_fn=torch.randn, partial_boxes=None):
     model = getattr(getattr(denoise_fn, "__self__", None), "model", None)
     if not isinstance(model, Unet1D):
         raise RuntimeError("graph sampling needs DiffusionPoint._denoise over a diffuscene_amd Unet1D")
     device = torch.device(device)
     with torch.no_grad():
         replay = isinstance(noise_fn, NoiseReplay)
-        key = (id(model), tuple(shape), str(device), bool(clip_denoised), diff.model_mean_type, replay,
+        pshape = None if partial_boxes is None else tuple(partial_boxes.shape)
+        key = (id(model), tuple(shape), str(device), bool(clip_denoised), diff.model_mean_type, replay, pshape,
                None if condition is None else (tuple(condition.shape), condition.stride(0) == 0),
                None if condition_cross is None else tuple(condition_cross.shape))
         g = diff._graphs.get(key)
         eng = model.engine(device)
         if g is None or g.plan is not eng.plans.get(_plan_key(g)):
-            g = _StepGraph(diff, model, tuple(shape), device, condition, condition_cross, clip_denoised, replay)
+            g = _StepGraph(diff, model, tuple(shape), device, condition, condition_cross, clip_denoised, replay, pshape)
             diff._graphs = {key: g}           # one live graph per diffusion object
         else:
             nch = len(g.plans)
@@ -144,9 +173,13 @@ def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cros
                             None if condition_cross is None else condition_cross[i * Bc:(i + 1) * Bc],
                             time_table=g.plan.time_table, slot=i)
         if replay:
-            return g.run(noise_fn.buffer[0], total_steps, noise_fn.buffer)
-        x_T = torch.randn(shape, dtype=torch.float, device=device)
-        return g.run(x_T, total_steps)
+            out = g.run(noise_fn.buffer[0], total_steps, noise_fn.buffer, partial_boxes, noise_fn.partial_buffer)
+        else:
+            x_T = torch.randn(shape, dtype=torch.float, device=device)
+            out = g.run(x_T, total_steps, partial=partial_boxes)
+        if partial_boxes is not None:
+            out[:, :partial_boxes.shape[1], :] = partial_boxes          # clean objects restored after the last step (:471-473)
+        return out
 
 
 def _plan_key(g):

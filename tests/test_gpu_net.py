@@ -155,6 +155,41 @@ def test_two_chain_graph_equals_eager_large_batch(monkeypatch):
     assert torch.equal(eager, graph)
 
 
+def test_graph_completion_text_arrange_match_reference(golden_dir):
+    """Every reverse loop through the captured hipGraph: completion (in-graph re-noising of the given objects), text
+    cross-attention and 5-channel re-arrangement reproduce the reference chains."""
+    from diffuscene_amd.sampler import NoiseReplay
+    g = np.load(os.path.join(golden_dir, "chains.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    net, diff = build("uncond_bedroom", time_num=50, model_mean_type="v")
+    shapes = [(B, N, C)]
+    for _ in range(50):
+        shapes += [(B, 3, C), (B, N, C)]
+    seq = noise_list(shapes, 2, "complete_")
+    main = torch.stack([seq[0]] + seq[2::2]).to(dev())
+    part = torch.stack(seq[1::2]).to(dev())
+    with torch.no_grad():
+        s = diff.complete_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(main, part),
+                                  clip_denoised=True, partial_boxes=x[:, :3, :].contiguous().to(dev()), graph=True)
+    assert rel(s, g["complete_T50"]) < TOL
+    kw, x, t, cond, cross = case_inputs("text_bedroom")
+    net, diff = build("text_bedroom", time_num=20, model_mean_type="v")
+    with torch.no_grad():
+        s = diff.gen_samples(tuple(x.shape), dev(), condition=cond.to(dev()), condition_cross=cross.to(dev()),
+                             noise_fn=_replay(noise_list([tuple(x.shape)] * 21, 4, "text_")), graph=True)
+    assert rel(s, g["text_T20"]) < TOL
+    kw, x, t, cond, _ = case_inputs("rearrange_living")
+    B, N = x.shape[:2]
+    full = W.synth_scene_batch(B, N, 25, 32, 5)
+    net, diff = build("rearrange_living", time_num=50, model_mean_type="v", config_extra={"room_arrange_condition": True})
+    with torch.no_grad():
+        s = diff.arrange_samples((B, N, 65), dev(), condition=cond.to(dev()),
+                                 noise_fn=_replay(noise_list([(B, N, 5)] * 51, 5, "arrange_")),
+                                 clip_denoised=True, input_boxes=full.to(dev()), graph=True)
+    assert rel(s, g["arrange_T50"]) < TOL
+
+
 def test_text_and_arrange_chains(golden_dir):
     g = np.load(os.path.join(golden_dir, "chains.npz"))
     kw, x, t, cond, cross = case_inputs("text_bedroom")
