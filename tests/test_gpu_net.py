@@ -81,6 +81,40 @@ def test_forward_matches_oracle_other_shapes(B, N, name):
     assert r < TOL
 
 
+@pytest.mark.parametrize("B,N", [(1, 4), (2, 160), (1, 80), (300, 5)])
+def test_forward_edge_shapes(B, N):
+    """smallest / largest scene sizes the fused kernels accept (4 and 160 objects), a single scene, and many tiny scenes
+    (ragged last tile); beyond 160 objects the call is rejected, not truncated."""
+    name = "uncond_living"
+    kw = CASES[name][0]
+    net, _ = build(name)
+    x = W.synth_scene_batch(B, N, 25, 32, seed=13)
+    t = torch.tensor([(5 + 97 * i) % 1000 for i in range(B)], dtype=torch.int64)
+    cond = W.synth_condition(B, N, 128, seed=13)
+    with torch.no_grad():
+        out = net(x.to(dev()), t.to(dev()), cond.to(dev()), None)
+        nb = min(B, 3)
+        ref = R.unet1d_forward(W.synth_state_dict(kw), kw, x[:nb], t[:nb], cond[:nb], None)
+    assert rel(out[:nb], ref) < TOL
+    if N == 160:
+        with pytest.raises(RuntimeError, match="160"):
+            net(torch.zeros(1, 161, 65, device=dev()), torch.zeros(1, dtype=torch.int64, device=dev()), None, None)
+
+
+def test_scripts_graph_switch_env(monkeypatch):
+    """DSC_GRAPH=1 routes the unchanged generate_layout() call through the captured graph."""
+    from diffuscene_amd import sampler
+    calls = []
+    orig = sampler.graph_sample_loop
+    monkeypatch.setattr(sampler, "graph_sample_loop", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setenv("DSC_GRAPH", "1")
+    net, diff = build("uncond_bedroom", time_num=5, model_mean_type="v")
+    cond = W.synth_condition(2, 12, 128, seed=1).to(dev())
+    with torch.no_grad():
+        s = diff.gen_samples((2, 12, 62), dev(), condition=cond, clip_denoised=True)
+    assert calls and torch.isfinite(s).all()
+
+
 def _replay(seq):
     from diffuscene_amd.sampler import NoiseReplay
     return NoiseReplay(torch.stack(seq).to(dev()))
