@@ -224,6 +224,18 @@ int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx, int64_t c
 int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t cols,
                       dsc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Shape retrieval: nearest database object of the same class in the 32-d latent shape-code space,
+ * ThreedFutureDataset.get_closest_furniture_to_objfeats (datasets/threed_future_dataset.py:49-59); with sizes
+ * (float64, [n][3]) the lexicographic (size mse, feature mse) order of ..._and_size (:61-77, np.lexsort).
+ * out_index[q] = database row, -1 when no object carries the label; ties -> lowest index.  Index-exact with the numpy
+ * reference (same fp32 summation order).
+ * ------------------------------------------------------------------------------------------- */
+int dsc_retrieve_nearest_f32(const float* query_feats, const int32_t* query_labels, const double* query_sizes,
+                             const float* db_feats, const int32_t* db_labels, const double* db_sizes,
+                             int32_t n_query, int32_t n_db, int32_t feat_dim, int32_t* out_index, float* out_dist,
+                             dsc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
