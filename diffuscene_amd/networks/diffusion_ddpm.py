@@ -26,6 +26,58 @@ ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
 _MEAN = {"eps": ops.MEAN_EPS, "x0": ops.MEAN_X0, "v": ops.MEAN_V}
 
 
+def identity(t, *args, **kwargs):
+    return t
+
+
+def norm(v, f):
+    v = (v - v.min()) / (v.max() - v.min()) - 0.5
+    return v, f
+
+
+def getGradNorm(net):
+    """(parameter norm, gradient norm), reference :28-31 -- two fused multi-tensor reductions instead of 2x|params| kernels."""
+    ps = [p for p in net.parameters()]
+    pNorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(ps)))
+    gradNorm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm([p.grad for p in ps])))
+    return pNorm, gradNorm
+
+
+def weights_init(m):
+    """xavier initialisation hook of the reference (:33-43)."""
+    classname = m.__class__.__name__
+    if classname.find('Conv') != -1 and getattr(m, "weight", None) is not None:
+        torch.nn.init.xavier_normal_(m.weight)
+    elif classname.find('BatchNorm') != -1:
+        m.weight.data.normal_()
+        m.bias.data.fill_(0)
+
+
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """KL divergence between diagonal normals given mean and log-variance (reference :94-99)."""
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2)
+                  + (mean1 - mean2) ** 2 * torch.exp(-logvar2))
+
+
+def discretized_gaussian_log_likelihood(x, *, means, log_scales):
+    """reference :101-121 (unused by the shipped configs; kept for surface parity)."""
+    assert x.shape == means.shape == log_scales.shape
+    px0 = torch.distributions.Normal(torch.zeros_like(means), torch.ones_like(log_scales))
+    centered_x = x - means
+    inv_stdv = torch.exp(-log_scales)
+    cdf_plus = px0.cdf(inv_stdv * (centered_x + 0.5))
+    cdf_min = px0.cdf(inv_stdv * (centered_x - .5))
+    log_cdf_plus = torch.log(torch.max(cdf_plus, torch.ones_like(cdf_plus) * 1e-12))
+    log_one_minus_cdf_min = torch.log(torch.max(1. - cdf_min, torch.ones_like(cdf_min) * 1e-12))
+    cdf_delta = cdf_plus - cdf_min
+    log_probs = torch.where(
+        x < 0.001, log_cdf_plus,
+        torch.where(x > 0.999, log_one_minus_cdf_min,
+                    torch.log(torch.max(cdf_delta, torch.ones_like(cdf_delta) * 1e-12))))
+    assert log_probs.shape == x.shape
+    return log_probs
+
+
 def get_betas(schedule_type, b_start, b_end, time_num):
     if schedule_type == 'linear':
         betas = np.linspace(b_start, b_end, time_num)
@@ -371,10 +423,18 @@ class GaussianDiffusion:
         if noise is None:
             noise = torch.randn(data_start.shape, dtype=data_start.dtype, device=data_start.device)
         assert noise.shape == data_start.shape and noise.dtype == data_start.dtype
-        if self.loss_type != 'mse':
-            # 'kl' (_vb_terms_bpd, :511-518) is a debugging path no shipped config selects
+        if self.loss_type not in ('mse', 'kl'):
             raise NotImplementedError(self.loss_type)
         tb = self.tables(data_start.device)
+        if self.loss_type == 'kl':
+            # reference :657-660 -- a (B,) tensor only, no loss dict
+            data_t = ops.q_sample(data_start.contiguous(), noise.contiguous(), t, tb["sqrt_alphas_cumprod"],
+                                  tb["sqrt_one_minus_alphas_cumprod"])
+            losses = self._vb_terms_bpd(denoise_fn=denoise_fn, data_start=data_start, data_t=data_t, t=t,
+                                        condition=condition, condition_cross=condition_cross, clip_denoised=False,
+                                        return_pred_xstart=False)
+            assert losses.shape == torch.Size([B])
+            return losses
         with torch.no_grad():
             data_t, v_target = ops.q_sample(data_start.contiguous(), noise.contiguous(), t, tb["sqrt_alphas_cumprod"],
                                             tb["sqrt_one_minus_alphas_cumprod"], want_v=True)
@@ -392,10 +452,57 @@ class GaussianDiffusion:
         from ..train_graph import diffusion_losses
         return diffusion_losses(self, tb, data_start, data_t, target, denoise_out, t)
 
+    def _vb_terms_bpd(self, denoise_fn, data_start, data_t, t, condition, condition_cross, clip_denoised: bool,
+                      return_pred_xstart: bool):
+        """KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) per scene in bits, reference :511-518."""
+        true_mean, _, true_log_variance_clipped = self.q_posterior_mean_variance(x_start=data_start, x_t=data_t, t=t)
+        model_mean, _, model_log_variance, pred_xstart = self.p_mean_variance(
+            denoise_fn, data=data_t, t=t, condition=condition, condition_cross=condition_cross,
+            clip_denoised=clip_denoised, return_pred_xstart=True)
+        kl = normal_kl(true_mean, true_log_variance_clipped, model_mean, model_log_variance)
+        kl = kl.mean(dim=list(range(1, len(data_start.shape)))) / np.log(2.)
+        return (kl, pred_xstart) if return_pred_xstart else kl
+
     def descale_to_origin(self, x, minimum, maximum):
         x = (x + 1) / 2
         x = x * (maximum - minimum)[None, None, :] + minimum[None, None, :]
         return x
+
+    # ------------------------------------------------------------------ diagnostics
+    def _prior_bpd(self, x_start):
+        """KL(q(x_T|x_0) || N(0,I)) per scene in bits, reference :679-688."""
+        with torch.no_grad():
+            B, T = x_start.shape[0], self.num_timesteps
+            t_ = torch.empty(B, dtype=torch.int64, device=x_start.device).fill_(T - 1)
+            qt_mean, _, qt_log_variance = self.q_mean_variance(x_start, t=t_)
+            kl_prior = normal_kl(mean1=qt_mean, logvar1=qt_log_variance,
+                                 mean2=torch.tensor([0.]).to(qt_mean), logvar2=torch.tensor([0.]).to(qt_log_variance))
+            assert kl_prior.shape == x_start.shape
+            return kl_prior.mean(dim=list(range(1, len(kl_prior.shape)))) / np.log(2.)
+
+    def calc_bpd_loop(self, denoise_fn, x_start, condition, condition_cross, clip_denoised=True):
+        """Variational bound over all T timesteps, reference :690-717.  Same draw order (one q_sample draw per
+        timestep, T-1 first); the (B,T) tables are filled by column instead of the reference's mask arithmetic."""
+        with torch.no_grad():
+            B, T = x_start.shape[0], self.num_timesteps
+            vals_bt_ = torch.zeros([B, T], device=x_start.device)
+            mse_bt_ = torch.zeros([B, T], device=x_start.device)
+            for t in reversed(range(T)):
+                t_b = torch.empty(B, dtype=torch.int64, device=x_start.device).fill_(t)
+                new_vals_b, pred_xstart = self._vb_terms_bpd(
+                    denoise_fn, data_start=x_start, data_t=self.q_sample(x_start=x_start, t=t_b), t=t_b,
+                    condition=condition, condition_cross=condition_cross, clip_denoised=clip_denoised,
+                    return_pred_xstart=True)
+                assert pred_xstart.shape == x_start.shape
+                new_mse_b = ((pred_xstart - x_start) ** 2).mean(dim=list(range(1, len(x_start.shape))))
+                assert new_vals_b.shape == new_mse_b.shape == torch.Size([B])
+                vals_bt_[:, t] = new_vals_b
+                mse_bt_[:, t] = new_mse_b
+            prior_bpd_b = self._prior_bpd(x_start)
+            total_bpd_b = vals_bt_.sum(dim=1) + prior_bpd_b
+            assert vals_bt_.shape == mse_bt_.shape == torch.Size([B, T]) and \
+                total_bpd_b.shape == prior_bpd_b.shape == torch.Size([B])
+            return total_bpd_b.mean(), vals_bt_.mean(), prior_bpd_b.mean(), mse_bt_.mean()
 
 
 def _use_graph(graph, noise_fn):
@@ -414,6 +521,14 @@ class DiffusionPoint(nn.Module):
         self.diffusion = GaussianDiffusion(config, betas, loss_type, model_mean_type, model_var_type, loss_separate,
                                            loss_iou, train_stats_file)
         self.model = denoise_net
+
+    def prior_kl(self, x0):
+        return self.diffusion._prior_bpd(x0)
+
+    def all_kl(self, x0, condition, condition_cross, clip_denoised=True):
+        total_bpd_b, vals_bt, prior_bpd_b, mse_bt = self.diffusion.calc_bpd_loop(self._denoise, x0, condition,
+                                                                                 condition_cross, clip_denoised)
+        return {'total_bpd_b': total_bpd_b, 'terms_bpd': vals_bt, 'prior_bpd_b': prior_bpd_b, 'mse_bt': mse_bt}
 
     def _denoise(self, data, t, condition, condition_cross):
         B, D, N = data.shape

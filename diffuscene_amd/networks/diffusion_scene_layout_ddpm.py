@@ -149,7 +149,11 @@ class DiffusionSceneLayout_DDPM(Module):
         batch_size, num_points, _ = class_labels.shape
         device = class_labels.device
         full = self.bbox_dim + self.class_dim + self.objectness_dim + self.objfeat_dim
-        if self.config["point_dim"] == full:
+        packed = sample_params.get("_packed")      # diffuscene_amd.datasets batches arrive already in channel order
+        if (self.config["point_dim"] == full and packed is not None and packed.shape[-1] == full
+                and self.objectness_dim == 0 and packed.is_contiguous()):
+            target = packed
+        elif self.config["point_dim"] == full:
             parts = [translations, sizes, angles, class_labels]
             if self.objectness_dim > 0:
                 parts.append(sample_params["objectness"])

@@ -236,6 +236,28 @@ int dsc_retrieve_nearest_f32(const float* query_feats, const int32_t* query_labe
                              int32_t n_query, int32_t n_db, int32_t feat_dim, int32_t* out_index, float* out_dist,
                              dsc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training input pipeline: one launch turns B scenes of the HBM-resident cached dataset into the padded
+ * (B, N, C) training batch -- RotationAugmentation (threed_front_dataset.py:313-371), Jitter (:559-567),
+ * Scale_CosinAngle_ObjfeatsNorm (:481-513), Permutation (:570-584) and the Diffusion padding wrapper (:888-925) fused.
+ * The random draws (rotation angle, jitter offsets, object order) are made on the host in the reference's order and
+ * passed in; the arithmetic follows numpy's mixed float32/float64 promotion (see oracle/dataset_ref.py).
+ *
+ * Store (device): offsets[S+1] first object row of each scene; class_labels[total][n_cls_in] one-hot incl. the start
+ * and end columns; translations/sizes [total][3]; angles [total]; objfeats [total][feat_dim] or NULL.
+ * Batch (device): scene[B]; order[B][N] (object j of the output comes from object order[b][j] of the scene; NULL =
+ * stored order); rot[B] radians or NULL (no rotation wrapper); jitter[B][3] (translation, size, angle offsets) or NULL.
+ * bounds (HOST, double): {t_lo[3], t_hi[3], s_lo[3], s_hi[3], angle_min, feat_lo, feat_hi}.
+ * out[B*N][ld_out] channel order [translation 3 | size 3 | cos, sin | class n_cls_in-1 | objfeat feat_dim]
+ * (diffusion_scene_layout_ddpm.py:148-154); rows >= length are the end symbol (class = [-1..-1,+1], rest 0).
+ * length[B] = number of objects.  Scenes longer than N are an error (DSC_EINVAL) detected on the host by the caller.
+ * ------------------------------------------------------------------------------------------- */
+int dsc_encode_scene_batch_f32(const int64_t* offsets, const float* class_labels, const float* translations,
+                               const float* sizes, const float* angles, const float* objfeats, int32_t n_cls_in,
+                               int32_t feat_dim, const int64_t* scene, const int32_t* order, const double* rot,
+                               const double* jitter, int32_t permute_objfeats, const double* bounds, float* out,
+                               int64_t ld_out, int64_t* length, int32_t b, int32_t n, dsc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,3 +297,35 @@ def test_scene_layout_wrapper_generates():
     n = boxes["translations"].shape[1]
     assert boxes["class_labels"].shape == (1, n, 21) and boxes["objfeats"].shape == (1, n, 32)
     assert all(v.device.type == "cpu" for v in boxes.values())
+
+
+def test_variational_bound_diagnostics_match_reference(golden_dir):
+    """loss_type 'kl', prior_kl and all_kl (diffusion_ddpm.py:511-518,657-660,679-745) against the real reference."""
+    from oracle.make_golden_bpd import T_LOOP
+    g = np.load(os.path.join(golden_dir, "bpd.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    noise = W.synth_noise(tuple(x.shape), 11, "bpd_q")
+    net, diff = build("uncond_bedroom", time_num=1000, model_mean_type="v")
+    gd = diff.diffusion
+    xd, td, cd = x.to(dev()), t.to(dev()), cond.to(dev())
+    with torch.no_grad():
+        x_t = gd.q_sample(xd, td, noise=noise.to(dev()))
+        for clip in (True, False):
+            kl, xr = gd._vb_terms_bpd(diff._denoise, data_start=xd, data_t=x_t, t=td, condition=cd, condition_cross=None,
+                                      clip_denoised=clip, return_pred_xstart=True)
+            assert rel(kl, g["vb_kl_clip%d" % clip]) < TOL
+            assert rel(xr, g["vb_xstart_clip%d" % clip]) < TOL
+        assert rel(diff.prior_kl(xd), g["prior_bpd"]) < TOL
+    _, diff_kl = build("uncond_bedroom", time_num=1000, model_mean_type="v", loss_type="kl")
+    with torch.no_grad():
+        losses = diff_kl.diffusion.p_losses(diff_kl._denoise, xd, td, noise=noise.to(dev()), condition=cd)
+    assert rel(losses, g["p_losses_kl"]) < TOL
+    _, diff20 = build("uncond_bedroom", time_num=T_LOOP, model_mean_type="v")
+    seq = noise_list([tuple(x.shape)] * T_LOOP, 12, "bpd_loop")
+    gd20 = diff20.diffusion
+    orig = gd20.q_sample
+    gd20.q_sample = lambda x_start, t, noise=None: orig(x_start, t, noise=seq[int(t[0])].to(dev()) if noise is None else noise)
+    r = diff20.all_kl(xd, cd, None, clip_denoised=True)
+    got = [float(r[k]) for k in ("total_bpd_b", "terms_bpd", "prior_bpd_b", "mse_bt")]
+    for a, b in zip(got, g["all_kl"]):
+        assert abs(a - b) <= 2e-4 * abs(b), (got, g["all_kl"])

@@ -121,3 +121,28 @@ def test_reverse_chain_T1000_matches_reference(golden_dir):
         s = R.p_sample_loop(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond[:1], None), (1, N, C),
                             noise_list([(1, N, C)] * 1001, 1, "chain1000_"), 1000, True)
     assert _rel(s, g["uncond_T1000"]) < 1e-4
+
+
+def test_variational_bound_terms_match_reference(golden_dir):
+    """loss_type 'kl' / prior_kl / all_kl restatements vs the real reference (oracle/make_golden_bpd.py)."""
+    from oracle.make_golden_bpd import T_LOOP
+    g = np.load(os.path.join(golden_dir, "bpd.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    sd = W.synth_state_dict(kw)
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    noise = W.synth_noise(tuple(x.shape), 11, "bpd_q")
+    den = lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None)
+    with torch.no_grad():
+        x_t = R.q_sample(tb, x, t, noise)
+        out = den(x_t, t)
+        for clip in (True, False):
+            kl, xr = R.vb_terms_bpd(tb, x, x_t, t, out, clip)
+            assert _rel(kl, g["vb_kl_clip%d" % clip]) < 5e-5
+            assert _rel(xr, g["vb_xstart_clip%d" % clip]) < RTOL
+        assert _rel(kl, g["p_losses_kl"]) < 5e-5
+        assert _rel(R.prior_bpd(tb, x), g["prior_bpd"]) < RTOL
+        tb20 = R.schedule_tables(1e-4, 0.02, T_LOOP, "v")
+        seq = noise_list([tuple(x.shape)] * T_LOOP, 12, "bpd_loop")
+        r = R.calc_bpd_loop(tb20, den, x, seq, True)
+    for a, b in zip(r, g["all_kl"]):
+        assert abs(float(a) - b) <= 1e-4 * abs(b)
