@@ -90,6 +90,10 @@ SIGNATURES = {
     "dsc_encode_scene_batch_f32": (C.c_int, [c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i64p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double), c_f32p,
                                              C.c_int64, c_i64p, C.c_int32, C.c_int32, C.c_void_p]),
+    "dsc_chamfer3d_forward_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_void_p]),
+    "dsc_chamfer3d_backward_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, c_f32p, c_f32p,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_ddpm_loss_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float),
                                     c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_void_p]),
     "dsc_activation_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),

@@ -258,6 +258,20 @@ int dsc_encode_scene_batch_f32(const int64_t* offsets, const float* class_labels
                                const double* jitter, int32_t permute_objfeats, const double* bounds, float* out,
                                int64_t ld_out, int64_t* length, int32_t b, int32_t n, dsc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3-D Chamfer distance -- the binding pair of ChamferDistancePytorch/chamfer3D/chamfer_cuda.cpp
+ * (chamfer_cuda_forward / chamfer_cuda_backward, kernels chamfer3D.cu:12-171).  xyz1 [b][n][3], xyz2 [b][m][3]
+ * contiguous fp32.  dist1[b][n] = squared distance from each point of cloud 1 to its nearest point of cloud 2,
+ * idx1 = that point's index (ties -> lowest index); dist2 / idx2 the other way round.  backward writes (does not
+ * accumulate into) gradxyz1 / gradxyz2 = d(sum graddist1*dist1 + sum graddist2*dist2)/d xyz; deterministic gather,
+ * no atomics.
+ * ------------------------------------------------------------------------------------------- */
+int dsc_chamfer3d_forward_f32(const float* xyz1, const float* xyz2, float* dist1, float* dist2, int32_t* idx1,
+                              int32_t* idx2, int32_t b, int32_t n, int32_t m, dsc_stream_t stream);
+int dsc_chamfer3d_backward_f32(const float* xyz1, const float* xyz2, const float* graddist1, const float* graddist2,
+                               const int32_t* idx1, const int32_t* idx2, float* gradxyz1, float* gradxyz2, int32_t b,
+                               int32_t n, int32_t m, dsc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
