@@ -20,8 +20,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     } while (0)
 
 __device__ __forceinline__ float dsc_silu(float x) { return x / (1.0f + expf(-x)); }
-// epilogue variant: hardware exp2/rcp (v_exp_f32, v_rcp_f32; ~1 ulp each), keeps the GEMM epilogue off the VALU critical path
-__device__ __forceinline__ float dsc_silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+// epilogue variant: hardware exp2/rcp (v_exp_f32, v_rcp_f32; ~1 ulp each), keeps the GEMM epilogue off the VALU critical path.
+// (__frcp_rn would expand to the correctly rounded ~10-instruction division sequence.)
+__device__ __forceinline__ float dsc_silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // nn.GELU() default: 0.5 x (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float dsc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

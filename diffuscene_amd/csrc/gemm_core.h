@@ -18,6 +18,7 @@
 // (lanes 0-31 carry k..k+3, lanes 32-63 carry k+4..k+7: the k-permutation is the same for both operands).
 // Register-staged prefetch of tile kt+1 overlaps the MFMAs of tile kt; two blocks per CU cover barriers.
 
+#include <type_traits>
 #include "dsc_common.h"
 
 #ifdef DSC_GEMM_TIMING          // tools/gemm_tune.hip only: per-block phase timestamps (shader clock)
@@ -35,7 +36,7 @@ namespace dsc_gemm {
 // PIPE (needs DB): MFMA fragments are software-pipelined one 8-wide K step ahead in registers, across the single
 // barrier per K tile, so one wave per SIMD can keep the matrix pipe busy on its own.
 template <int TM, int TN, int WM, int WN, bool GN, int BK = 32, bool DB = false, int MINW = 2, bool XCD = false,
-          bool PIPE = false>
+          bool PIPE = false, bool EPF = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm_args p, const int ncolblk) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -272,6 +273,27 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     float* patch = smem + SCR + wave * (32 * TLD);
     const int tr = lane >> 3, cq = lane & 7;
 
+    // EPF: every residual quad this lane will add is requested NOW, ahead of the GroupNorm statistics, so the HBM latency
+    // of the residual stream hides behind the stats phase instead of being paid tile by tile (the staging / fragment
+    // registers of the main loop are dead here, so the 16*TM*TN extra VGPRs stay inside the main loop's allocation).
+    f32x4 rpre[EPF ? TM * TN * 4 : 1];
+    const bool use_pre = EPF && rfast && (GN || fast);
+    if constexpr (EPF) {
+        if (use_pre) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
+                        const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
+                        const int tlc = tl < rows_here ? tl : 0;
+                        rpre[(tn * TM + tm) * 4 + i] = *reinterpret_cast<const f32x4*>(res + (row0 + tlc) * p.ldr + c);
+                    }
+        }
+    }
+
     if constexpr (GN) {
         constexpr int G = BN / 64;        // GroupNorm groups covered by this block
         constexpr int CT = BN / 32;       // 32-channel tiles in the block
@@ -342,8 +364,36 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             if (lane == 0) stat[spt * G + st] = 1.0f / sqrtf(s * inv_cnt + p.eps);
         }
         __syncthreads();
+        // Per-row tables so that the store loop below has no integer division and no conditioning-mode branches:
+        // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index.
+        // Blocks are scene-aligned, so the first scene of the block is rb * spt.
+        float* rowst = smem;                                        // [G][BM][2]
+        int* rowss = reinterpret_cast<int*>(stat + 192);            // [BM]; stat holds at most 2 * 40 * 2 floats
+        {
+            const int64_t scene0 = (int64_t)rb * spt;
+            for (int t = tid; t < BM; t += T) {
+                const int sc = t / N;
+                const bool ok = t < rows_here;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    rowst[(g * BM + t) * 2 + 0] = ok ? stat[sc * G + g] : 0.f;
+                    rowst[(g * BM + t) * 2 + 1] = ok ? stat[spt * G + sc * G + g] : 0.f;
+                }
+                int ssr = 0;
+                if (p.scale_shift && ok) {
+                    if (p.ss_mode == DSC_SS_PER_SCENE) ssr = (int)(scene0 + sc);
+                    else if (p.ss_mode == DSC_SS_PER_SLOT) ssr = t - sc * N;
+                    else if (p.ss_mode == DSC_SS_BY_INDEX) ssr = (int)p.ss_index[scene0 + sc];
+                    else ssr = (int)(row0 + t);
+                }
+                rowss[t] = ssr;
+            }
+        }
+        __syncthreads();
         DSC_STAMP(3);
         float* zp = p.preact ? p.preact + (int64_t)z * p.sy : nullptr;
+        const bool yfast = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+        const bool has_ss = p.scale_shift != nullptr;
         // normalise, affine, scale/shift, SiLU, residual, store -- in the transposed (row-major) patch layout
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -351,6 +401,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
             const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
             const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+            const int tl0 = wm * TM * 32 + tr;
+            float* yp = y + (row0 + tl0) * p.ldy + c;               // running row pointers: +8 rows per step
+            float* zq = zp ? zp + (row0 + tl0) * p.ld_preact + c : nullptr;
+            const int64_t ystep = 8 * p.ldy, zstep = 8 * p.ld_preact;
+            const float* ssb = has_ss ? p.scale_shift + c : nullptr;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -363,81 +418,95 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
+                    const int tl = tl0 + tm * 32 + 8 * i;
                     if (tl < rows_here) {
-                        const int64_t tok = row0 + tl;
-                        const int sc = tl / N;
-                        const float mu = stat[sc * G + g];
-                        const float rs = stat[spt * G + sc * G + g];
+                        const float mu = rowst[(g * BM + tl) * 2 + 0];
+                        const float rs = rowst[(g * BM + tl) * 2 + 1];
                         f32x4 v = *reinterpret_cast<const f32x4*>(patch + (tr + 8 * i) * TLD + cq * 4);
-                        if (zp) *reinterpret_cast<f32x4*>(zp + tok * p.ld_preact + c) = v;
+                        if (zq) *reinterpret_cast<f32x4*>(zq) = v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) * rs * ga[e] + be[e];
-                        if (p.scale_shift) {
-                            int64_t ssrow = tok;
-                            if (p.ss_mode == DSC_SS_PER_SCENE) ssrow = tok / N;
-                            else if (p.ss_mode == DSC_SS_PER_SLOT) ssrow = tok % N;
-                            else if (p.ss_mode == DSC_SS_BY_INDEX) ssrow = p.ss_index[tok / N];
-                            const float* ss = p.scale_shift + ssrow * p.ld_ss;
-                            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss + c);
-                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + p.n + c);
+                        if (has_ss) {
+                            const float* ss = ssb + (int64_t)rowss[tl] * p.ld_ss;
+                            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
+                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + p.n);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] * (sc4[e] + 1.0f) + sh4[e];
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = dsc_silu_fast(v[e]);
                         if (res) {
-                            if (rfast) {
-                                const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + tok * p.ldr + c);
+                            if (EPF && use_pre) {
+                                const f32x4 r4 = rpre[(tn * TM + tm) * 4 + i];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                            } else if (rfast) {
+                                const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + (row0 + tl) * p.ldr + c);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += r4[e];
                             } else {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += res[tok * p.ldr + c + e];
+                                for (int e = 0; e < 4; ++e) v[e] += res[(row0 + tl) * p.ldr + c + e];
                             }
                         }
-                        if ((p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
-                            *reinterpret_cast<f32x4*>(y + tok * p.ldy + c) = v;
+                        if (yfast)
+                            *reinterpret_cast<f32x4*>(yp) = v;
                         else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) y[tok * p.ldy + c + e] = v[e];
+                            for (int e = 0; e < 4; ++e) yp[e] = v[e];
                         }
                     }
+                    yp += ystep;
+                    if (zq) zq += zstep;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
     } else if (fast) {
+        // one copy of the store loop per output activation: the erf-GELU polynomial must not sit (branched over) in the
+        // plain store path
+        auto plain_store = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
+            const int tl0 = wm * TM * 32 + tr;
+            float* yp = y + (row0 + tl0) * p.ldy + c;               // running row pointers: +8 rows per step
+            const float* rp = res ? res + (row0 + tl0) * p.ldr + c : nullptr;
+            const int64_t ystep = 8 * p.ldy, rstep = 8 * p.ldr;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dsc_act(acc[tm][tn][4 * q + e], p.act_out);
+                    for (int e = 0; e < 4; ++e) v[e] = dsc_act(acc[tm][tn][4 * q + e], ACT);
                     *reinterpret_cast<f32x4*>(patch + l31 * TLD + 8 * q + 4 * half) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
+                    const int tl = tl0 + tm * 32 + 8 * i;
                     if (tl < rows_here) {
-                        const int64_t tok = row0 + tl;
                         f32x4 v = *reinterpret_cast<const f32x4*>(patch + (tr + 8 * i) * TLD + cq * 4);
                         if (res) {
-                            const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + tok * p.ldr + c);
+                            const f32x4 r4 = (EPF && use_pre) ? rpre[(tn * TM + tm) * 4 + i]
+                                                              : *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] += r4[e];
                         }
-                        *reinterpret_cast<f32x4*>(y + tok * p.ldy + c) = v;
+                        *reinterpret_cast<f32x4*>(yp) = v;
                     }
+                    yp += ystep;
+                    if (rp) rp += rstep;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        };
+        if (p.act_out == DSC_ACT_GELU) plain_store(std::integral_constant<int, DSC_ACT_GELU>{});
+        else if (p.act_out == DSC_ACT_SILU) plain_store(std::integral_constant<int, DSC_ACT_SILU>{});
+        else plain_store(std::integral_constant<int, DSC_ACT_NONE>{});
     } else {
         // ragged / unaligned outputs (narrow decoder heads written at a column offset of the (M, C) tensor)
 #pragma unroll

@@ -11,17 +11,20 @@ extern "C" int tune_read_timing(long long* host, int nblocks) {
 
 using dsc_gemm::gemm_kernel;
 
-template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false>
+template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false, bool EPF = false>
 static int run(const dsc_gemm_args* a, hipStream_t s, int stagger) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
     const int nrb = (a->m + rpb - 1) / rpb, ncb = (a->n + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE, EPF>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
     return (int)hipGetLastError();
 }
 
 #define VP(id, TM, TN, WM, WN, BK, MINW) \
     case id: return gn ? run<TM, TN, WM, WN, true, BK, true, MINW, true, true>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, true, MINW, true, true>(a, s, stagger);
+
+#define VE(id, TM, TN, WM, WN, BK, MINW) \
+    case id: return gn ? run<TM, TN, WM, WN, true, BK, false, MINW, true, false, true>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, false, MINW, true, false, true>(a, s, stagger);
 
 #define V(id, TM, TN, WM, WN, BK, DB, MINW, XCD) \
     case id: return gn ? run<TM, TN, WM, WN, true, BK, DB, MINW, XCD>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, DB, MINW, XCD>(a, s, stagger);
@@ -54,6 +57,8 @@ extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* s
         V(20, 2, 1, 2, 2, 32, false, 4, true)
         V(21, 3, 1, 1, 4, 32, false, 3, true)
         V(22, 1, 2, 2, 2, 32, false, 4, true)
+        VE(23, 5, 1, 1, 4, 32, 2)
+        VE(24, 5, 1, 1, 8, 64, 2)
     }
     return -1;
 }
@@ -68,6 +73,7 @@ extern "C" const char* tune_name(int variant) {
         "11: 160x256 8w BK16 DB + XCD", "12: 160x256 4w(5x2) BK16 DB + XCD",
         "13: PIPE 160x128 4w BK16 (2 blk/CU)", "14: PIPE 160x256 8w BK32 (1 blk/CU)", "15: PIPE 160x256 8w BK16",
         "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD",
-        "18: 64x64 4w (many small blocks)", "19: 128x128 4w 3 waves/SIMD", "20: 128x64 4w", "21: 96x128 4w", "22: 64x128 4w"};
-    return (variant >= 0 && variant < 23) ? names[variant] : nullptr;
+        "18: 64x64 4w (many small blocks)", "19: 128x128 4w 3 waves/SIMD", "20: 128x64 4w", "21: 96x128 4w", "22: 64x128 4w",
+        "23: product 160x128 4w + epilogue residual prefetch", "24: product 160x256 8w BK64 + epilogue residual prefetch"};
+    return (variant >= 0 && variant < 25) ? names[variant] : nullptr;
 }

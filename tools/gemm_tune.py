@@ -25,6 +25,12 @@ def main():
     lib.tune_launch.argtypes = [C.c_int, C.c_int, C.POINTER(_lib.GemmArgs), C.c_void_p]
     lib.tune_name.restype = C.c_char_p
     dev = torch.device("cuda:0")
+    only = None
+    for a_ in sys.argv[1:]:
+        if a_.startswith("--only="):
+            only = [int(x) for x in a_[7:].split(",")]
+    nores = "--nores" in sys.argv
+    NV = 25
     B, N = 256, 80
     M = B * N
     torch.manual_seed(0)
@@ -39,15 +45,18 @@ def main():
         r = torch.randn(M, 512, device=dev)
         for gn in (0, 1):
             ref = None
-            for v in range(23):
+            for v in (only if only is not None else range(NV)):
                 y = torch.zeros(M, 512, device=dev)
-                if gn and v >= 18:
+                if gn and 18 <= v <= 22:
                     continue                     # small tiles cannot hold an 80-token scene
+                if gn and v in (7, 24):
+                    continue                     # 8-wave BK64 tile is a plain-GEMM tile
+                rr = None if nores else r
                 if gn:
-                    g = ops.make_gemm_args(a, w, y, b, a2, r, gamma=gamma, beta=beta, tokens_per_scene=N,
+                    g = ops.make_gemm_args(a, w, y, b, a2, rr, gamma=gamma, beta=beta, tokens_per_scene=N,
                                            scale_shift=ss, ss_mode=2)
                 else:
-                    g = ops.make_gemm_args(a, w, y, b, a2, r)
+                    g = ops.make_gemm_args(a, w, y, b, a2, rr)
                 s = ops.stream_ptr()
                 rc = lib.tune_launch(v, gn, C.byref(g), s)
                 torch.cuda.synchronize()
@@ -75,13 +84,14 @@ def main():
     import numpy as np
     lib.tune_read_timing.argtypes = [C.c_void_p, C.c_int]
     for gn in (0, 1):
-        for v in (1, 13, 14):
+        for v in ((1, 23) if only is not None else (1, 13, 14)):
             a = torch.randn(M, 512, device=dev); w = torch.randn(512, 512, device=dev) * 0.05
             y = torch.zeros(M, 512, device=dev)
+            rr = None if nores else r
             if gn:
-                g = ops.make_gemm_args(a, w, y, b, None, r, gamma=gamma, beta=beta, tokens_per_scene=N, scale_shift=ss, ss_mode=2)
+                g = ops.make_gemm_args(a, w, y, b, None, rr, gamma=gamma, beta=beta, tokens_per_scene=N, scale_shift=ss, ss_mode=2)
             else:
-                g = ops.make_gemm_args(a, w, y, b, None, r)
+                g = ops.make_gemm_args(a, w, y, b, None, rr)
             for _ in range(3):
                 lib.tune_launch(v, gn, C.byref(g), ops.stream_ptr())
             torch.cuda.synchronize()
@@ -110,7 +120,7 @@ def main():
                 print("   %-12s %9.0f [%9.0f .. %9.0f]" % (nm, col.mean(), col.min(), col.max()))
     print("\nfit T = a + b*K (us):")
     for gn in (0, 1):
-        for v in range(23):
+        for v in range(NV):
             if (512, gn, v) in res and (1024, gn, v) in res:
                 t1, t2 = res[(512, gn, v)], res[(1024, gn, v)]
                 bb = (t2 - t1) / 512
