@@ -134,9 +134,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 // out[i] = sum_s slabs[s][i]   (deterministic order)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long slab, int nslab, float* __restrict__ out,
                                     long count) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
-    for (; i < count; i += stride) {
+    const long tid0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((slab | count) & 3) == 0 && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        // 16-byte lanes, 4 slabs in flight per thread; slab order of the sum is fixed (k ascending within each of 4 chains)
+        for (long i = tid0 * 4; i < count; i += stride * 4) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            int k = 0;
+            for (; k + 3 < nslab; k += 4) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + (long)k * slab + i);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (long)(k + 1) * slab + i);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (long)(k + 2) * slab + i);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (long)(k + 3) * slab + i);
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; k < nslab; ++k) a0 += *reinterpret_cast<const f32x4*>(slabs + (long)k * slab + i);
+            *reinterpret_cast<f32x4*>(out + i) = (a0 + a1) + (a2 + a3);
+        }
+        return;
+    }
+    for (long i = tid0; i < count; i += stride) {
         float s = 0.f;
         for (int k = 0; k < nslab; ++k) s += slabs[(long)k * slab + i];
         out[i] = s;
@@ -152,8 +169,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const long r0 = (long)blockIdx.y * chunk;
     const long r1 = (r0 + chunk < m) ? r0 + chunk : m;
     float s = 0.f;
-    if (c < n)
-        for (long r = r0 + rq; r < r1; r += 4) s += x[r * ldx + c];
+    if (c < n) {
+        // 8 independent loads in flight per thread (the plain loop serialises on the load latency)
+        const float* xp = x + (r0 + rq) * ldx + c;
+        const long step = 4 * ldx;
+        long r = r0 + rq;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; r + 28 < r1; r += 32, xp += 8 * step) {
+            const float v0 = xp[0], v1 = xp[step], v2 = xp[2 * step], v3 = xp[3 * step];
+            const float v4 = xp[4 * step], v5 = xp[5 * step], v6 = xp[6 * step], v7 = xp[7 * step];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        for (; r < r1; r += 4, xp += step) s0 += xp[0];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[rq][threadIdx.x & 63] = s;
     __syncthreads();
     if (rq == 0 && c < n) partial[(long)blockIdx.y * n + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
@@ -188,68 +218,84 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Every thread owns one channel and every 4th token of the (scene, group) tile.  Its z / dy elements are read from HBM
+// ONCE and parked in a thread-private LDS column (a register file spill area indexed by token: no barriers needed for
+// it); the normalised activation and d(xhat) replace them after the first sweep, so the expensive SiLU derivative is
+// evaluated once per element and the kernel moves exactly z + dy in, dz out.
 __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const GnBwdArgs p) {
+    extern __shared__ float gnb_cache[];          // [2][N][64]
     __shared__ float red[4];
-    __shared__ float csum[6][4][64];
+    __shared__ float csum[5][4][64];
     const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
     const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6;
     const int c = g * 64 + cl;
     const int N = p.n_tok;
     const long tok0 = (long)b * N;
     const float inv_cnt = 1.0f / (64.0f * (float)N);
-    // statistics of the group (two passes, as the forward)
+    float* zc = gnb_cache + cl;                   // zc[j * 64]
+    float* dc = gnb_cache + (long)N * 64 + cl;
+    // load sweep: both streams in flight together
     float s = 0.f;
-    for (int j = tq; j < N; j += 4) s += p.z[(tok0 + j) * p.ldz + c];
+    {
+        const float* zp = p.z + (tok0 + tq) * p.ldz + c;
+        const float* dp = p.dy + (tok0 + tq) * p.ldy + c;
+        const long zs = 4 * p.ldz, ds = 4 * p.ldy;
+#pragma unroll 5
+        for (int j = tq; j < N; j += 4) {
+            const float zv = *zp, dv = *dp;
+            zp += zs; dp += ds;
+            zc[j * 64] = zv; dc[j * 64] = dv;
+            s += zv;
+        }
+    }
+    // statistics of the group (two passes, as the forward)
     const float mu = block_sum(s, red) * inv_cnt;
     s = 0.f;
-    for (int j = tq; j < N; j += 4) { const float d = p.z[(tok0 + j) * p.ldz + c] - mu; s += d * d; }
+    for (int j = tq; j < N; j += 4) { const float d = zc[j * 64] - mu; s += d * d; }
     const float rs = 1.0f / sqrtf(block_sum(s, red) * inv_cnt + p.eps);
     const float ga = p.gamma[c], be = p.beta[c];
 
-    auto ss_row = [&](long tok) -> const float* {
-        if (p.ss_mode == DSC_SS_PER_TOKEN) return p.ss + tok * p.ld_ss;
-        if (p.ss_mode == DSC_SS_PER_SCENE) return p.ss + (long)b * p.ld_ss;
-        if (p.ss_mode == DSC_SS_PER_SLOT) return p.ss + (tok - tok0) * p.ld_ss;
-        return nullptr;
-    };
-    // pass 1: group means of dxh and dxh*xh, per-channel sums
+    const float* ssb = nullptr;                   // scale/shift row of token j: ssb + j * ss_step
+    long ss_step = 0;
+    if (p.ss) {
+        if (p.ss_mode == DSC_SS_PER_TOKEN) { ssb = p.ss + tok0 * p.ld_ss; ss_step = p.ld_ss; }
+        else if (p.ss_mode == DSC_SS_PER_SCENE) { ssb = p.ss + (long)b * p.ld_ss; ss_step = 0; }
+        else if (p.ss_mode == DSC_SS_PER_SLOT) { ssb = p.ss; ss_step = p.ld_ss; }
+    }
+    const bool dss_rows = p.dss && p.ss_mode != DSC_SS_PER_SCENE && ssb;
+    // sweep 1: d(xhat) of every element, group means of dxh and dxh*xh, per-channel sums
     float S1 = 0.f, S2 = 0.f, Gg = 0.f, Gb = 0.f, Gsc = 0.f, Gsh = 0.f;
     for (int j = tq; j < N; j += 4) {
-        const long tok = tok0 + j;
-        const float xh = (p.z[tok * p.ldz + c] - mu) * rs;
+        const float xh = (zc[j * 64] - mu) * rs;
         const float gh = ga * xh + be;
         float s1 = 1.0f, sh = 0.f;
-        const float* sr = ss_row(tok);
-        if (sr) { s1 = 1.0f + sr[c]; sh = sr[p.C + c]; }
+        if (ssb) { const float* sr = ssb + (long)j * ss_step; s1 = 1.0f + sr[c]; sh = sr[p.C + c]; }
         const float u = gh * s1 + sh;
-        const float sig = 1.0f / (1.0f + expf(-u));
-        const float du = p.dy[tok * p.ldy + c] * (sig * (1.0f + u * (1.0f - sig)));
+        const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        const float du = dc[j * 64] * (sig * (1.0f + u * (1.0f - sig)));
         const float dgh = du * s1;
         const float dxh = dgh * ga;
         S1 += dxh; S2 += dxh * xh; Gg += dgh * xh; Gb += dgh; Gsc += du * gh; Gsh += du;
-        if (p.dss && p.ss_mode != DSC_SS_PER_SCENE && sr) {
-            p.dss[tok * p.ld_dss + c] = du * gh;
-            p.dss[tok * p.ld_dss + p.C + c] = du;
+        if (dss_rows) {
+            p.dss[(tok0 + j) * p.ld_dss + c] = du * gh;
+            p.dss[(tok0 + j) * p.ld_dss + p.C + c] = du;
         }
+        zc[j * 64] = xh;
+        dc[j * 64] = dxh;
     }
     const float m1 = block_sum(S1, red) * inv_cnt;
     const float m2 = block_sum(S2, red) * inv_cnt;
-    // pass 2: dz and its per-channel sum (bias gradient)
+    // sweep 2: dz and its per-channel sum (bias gradient)
     float Gz = 0.f;
-    for (int j = tq; j < N; j += 4) {
-        const long tok = tok0 + j;
-        const float xh = (p.z[tok * p.ldz + c] - mu) * rs;
-        const float gh = ga * xh + be;
-        float s1 = 1.0f, sh = 0.f;
-        const float* sr = ss_row(tok);
-        if (sr) { s1 = 1.0f + sr[c]; sh = sr[p.C + c]; }
-        const float u = gh * s1 + sh;
-        const float sig = 1.0f / (1.0f + expf(-u));
-        const float du = p.dy[tok * p.ldy + c] * (sig * (1.0f + u * (1.0f - sig)));
-        const float dxh = du * s1 * ga;
-        const float dzv = rs * (dxh - m1 - xh * m2);
-        p.dz[tok * p.lddz + c] = dzv;
-        Gz += dzv;
+    {
+        float* op = p.dz + (tok0 + tq) * p.lddz + c;
+        const long os = 4 * p.lddz;
+        for (int j = tq; j < N; j += 4) {
+            const float dzv = rs * (dc[j * 64] - m1 - zc[j * 64] * m2);
+            *op = dzv;
+            op += os;
+            Gz += dzv;
+        }
     }
     csum[0][tq][cl] = Gg; csum[1][tq][cl] = Gb; csum[2][tq][cl] = Gz; csum[3][tq][cl] = Gsc; csum[4][tq][cl] = Gsh;
     __syncthreads();
@@ -759,7 +805,7 @@ extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const 
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(ktiles * ntiles, splits), dim3(256), 0, s, p);
     DSC_LAUNCH_CHECK();
     if (splits > 1) {
-        long blocks = (wslab + 255) / 256;
+        long blocks = ((wslab & 3) == 0) ? (wslab / 4 + 255) / 256 : (wslab + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         DSC_CLEAR_STALE_ERROR();
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, wslab, splits, out, wslab);
@@ -815,8 +861,19 @@ extern "C" int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy,
     GnBwdArgs p{z, (long)ldz, dy, (long)ldy, gamma, beta, ss_mode != DSC_SS_NONE ? scale_shift : nullptr, (long)ld_ss,
                 ss_mode, dz, (long)lddz, dgamma_p, dbeta_p, dbias_p, (long)partial_stride, dss, (long)ld_dss, tokens_per_scene,
                 channels, eps};
+    if (tokens_per_scene > 160) return DSC_ERANGE;
+    const size_t lds = (size_t)2 * tokens_per_scene * 64 * sizeof(float);      // <= 80 KB
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(scenes * 8), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_silu_bwd_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(gn_silu_bwd_kernel, dim3(scenes * 8), dim3(256), lds, static_cast<hipStream_t>(stream), p);
     DSC_LAUNCH_CHECK();
     return 0;
 }

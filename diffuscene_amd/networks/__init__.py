@@ -16,7 +16,9 @@ def optimizer_factory(config, parameters):
     if optimizer == "SGD":
         return torch.optim.SGD(parameters, lr=lr, momentum=momentum, weight_decay=0.0)
     elif optimizer == "Adam":
-        return torch.optim.Adam(parameters, lr=lr, weight_decay=0.0)
+        # a torch.optim.Adam whose step() is the fused HIP clip+Adam sweep (diffuscene_amd/optim.py)
+        from ..optim import FusedAdam
+        return FusedAdam(parameters, lr=lr, weight_decay=0.0)
     elif optimizer == "RAdam":
         return torch.optim.RAdam(parameters, lr=lr, weight_decay=0.0)
     raise NotImplementedError()

@@ -287,7 +287,10 @@ def train_on_batch(model, optimizer, sample_params, config):
     loss, loss_dict = model.get_loss(sample_params)
     loss.backward()
     average_gradients(model)
-    grad_norm = clip_grad_norm_fused(model.parameters(), config["training"]["max_grad_norm"])
+    if hasattr(optimizer, "clip_grad_norm_"):         # FusedAdam: norm + coefficient on the device, applied in step()
+        grad_norm = optimizer.clip_grad_norm_(config["training"]["max_grad_norm"])
+    else:
+        grad_norm = clip_grad_norm_fused(model.parameters(), config["training"]["max_grad_norm"])
     keys = list(loss_dict.keys())
     packed = torch.stack([loss.detach(), grad_norm.detach()] + [loss_dict[k].detach() for k in keys]).tolist()
     logger = StatsLogger.instance()

@@ -272,6 +272,30 @@ int dsc_chamfer3d_backward_f32(const float* xyz1, const float* xyz2, const float
                                const int32_t* idx1, const int32_t* idx2, float* gradxyz1, float* gradxyz2, int32_t b,
                                int32_t n, int32_t m, dsc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step of train_on_batch (diffusion_scene_layout_ddpm.py:456-473): torch.nn.utils.clip_grad_norm_ +
+ * torch.optim.Adam (networks/__init__.py:29-30) as three launches over a DEVICE work list of chunks (each <= 32768
+ * contiguous elements of one parameter; pointers are device pointers).  Nothing is synchronised with the host: the
+ * total norm and the clip coefficient stay in device memory and dsc_adam_step_f32 multiplies every gradient by
+ * *grad_scale (NULL = 1) while it reads it.  Arithmetic of torch.optim.Adam (amsgrad=False, maximize=False):
+ *   g += weight_decay * p;  m += (g - m)(1 - beta1);  v = v beta2 + (1 - beta2) g g;
+ *   p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps),   step_size = lr / (1 - beta1^t).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dsc_optim_chunk {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t count;
+} dsc_optim_chunk;
+
+int dsc_grad_sumsq_f32(const dsc_optim_chunk* chunks, int32_t nchunks, double* partial, dsc_stream_t stream);
+int dsc_clip_coef_f32(const double* partial, int32_t nchunks, float max_norm, float* total_norm, float* clip_coef,
+                      dsc_stream_t stream);
+int dsc_adam_step_f32(const dsc_optim_chunk* chunks, int32_t nchunks, float step_size, float beta1, float beta2,
+                      float bias_correction2_sqrt, float eps, float weight_decay, const float* grad_scale,
+                      dsc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

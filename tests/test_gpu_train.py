@@ -352,3 +352,44 @@ def test_train_on_batch_runs_and_learns(tmp_path):
     assert all(np.isfinite(ls)) and ls[-1] < 0.8 * ls[0]
     assert StatsLogger.instance()["gradnorm"].value > 0
     assert m.positional_embedding.grad is not None and float(m.positional_embedding.grad.abs().sum()) > 0
+
+
+def test_fused_adam_matches_torch_adam_with_clipping():
+    """FusedAdam (csrc/optim.hip) vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over several steps, incl. odd
+    sizes, a tensor spanning several chunks and a state_dict round trip into a plain torch.optim.Adam."""
+    from diffuscene_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(512, 512), (70001,), (3, 5, 7), (1,), (2048, 64), (13,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=dev()) * 0.3) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=2e-3, weight_decay=0.0)
+    mine = FusedAdam(my_p, lr=2e-3, weight_decay=0.0)
+    for it in range(4):
+        gs = [torch.randn(s, device=dev()) * (5.0 if it % 2 == 0 else 0.01) for s in shapes]     # clipped / unclipped steps
+        for p, q, g in zip(ref_p, my_p, gs):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref_p, 10.0)
+        n_my = mine.clip_grad_norm_(10.0)
+        assert abs(float(n_ref) - float(n_my)) <= 1e-5 * float(n_ref)
+        ref.step()
+        mine.step()
+        for p, q in zip(ref_p, my_p):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (it, p.shape, float((p - q).abs().max()))
+    sd = mine.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0
+    import copy
+    ref.load_state_dict(copy.deepcopy(sd))                            # interchangeable checkpoint format (deep copies:
+    mine2 = FusedAdam(my_p, lr=2e-3)                                  #  load_state_dict aliases same-device tensors)
+    mine2.load_state_dict(copy.deepcopy(ref.state_dict()))
+    for p, q in zip(ref_p, my_p):
+        g = torch.randn_like(p)
+        p.grad, q.grad = g.clone(), g.clone()
+    ref.step()
+    mine2.step()                                                      # no clip call: coefficient must not be applied
+    for p, q in zip(ref_p, my_p):
+        assert torch.allclose(p, q, rtol=2e-6, atol=1e-7)
+    cpu = FusedAdam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3)
+    cpu.param_groups[0]["params"][0].grad = torch.ones(4)
+    with pytest.raises(RuntimeError):
+        cpu.step()
