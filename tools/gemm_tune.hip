@@ -77,3 +77,88 @@ extern "C" const char* tune_name(int variant) {
         "23: product 160x128 4w + epilogue residual prefetch", "24: product 160x256 8w BK64 + epilogue residual prefetch"};
     return (variant >= 0 && variant < 25) ? names[variant] : nullptr;
 }
+
+// ---- scene-resident layer kernel (diffuscene_amd/csrc/scene_core.h): one block of 512 threads per scene -------------
+#include "scene_core.h"
+
+template <bool GN>
+__global__ __launch_bounds__(512, 1) void scene_layer_kernel(const dsc_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) float scene_smem[];
+    dsc_scene::scene_gemm<GN, 0>(p, blockIdx.x, p.tokens_per_scene, scene_smem);
+}
+
+template <bool GN>
+__global__ __launch_bounds__(512, 1) void scene_layer_direct_kernel(const dsc_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) float scene_smem[];
+    dsc_scene::scene_gemm<GN, 2>(p, blockIdx.x, p.tokens_per_scene, scene_smem);
+}
+
+template <int PROBE>
+__global__ __launch_bounds__(512, 1) void scene_layer_probe_kernel(const dsc_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) float scene_smem[];
+    dsc_scene::scene_gemm<true, 2, PROBE>(p, blockIdx.x, p.tokens_per_scene, scene_smem);
+}
+extern "C" int tune_scene_probe_launch(int probe, const dsc_gemm_args* a, void* stream) {
+    const int scenes = a->m / a->tokens_per_scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = dsc_scene::SC_WP_SMEM_FLOATS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_probe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_probe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (probe == 1) hipLaunchKernelGGL(scene_layer_probe_kernel<1>, dim3(scenes), dim3(512), lds, s, *a);
+    else hipLaunchKernelGGL(scene_layer_probe_kernel<2>, dim3(scenes), dim3(512), lds, s, *a);
+    return (int)hipGetLastError();
+}
+
+template <bool GN, int PROBE>
+__global__ __launch_bounds__(512, 1) void scene_layer_frag_kernel(const dsc_gemm_args p) {
+    dsc_scene::scene_gemm<GN, 3, PROBE>(p, blockIdx.x, p.tokens_per_scene, nullptr);
+}
+extern "C" int tune_scene_frag_launch(int gn, int probe, const dsc_gemm_args* a, void* stream) {
+    const int scenes = a->m / a->tokens_per_scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (probe == 1) hipLaunchKernelGGL((scene_layer_frag_kernel<true, 1>), dim3(scenes), dim3(512), 0, s, *a);
+    else if (probe == 2) hipLaunchKernelGGL((scene_layer_frag_kernel<true, 2>), dim3(scenes), dim3(512), 0, s, *a);
+    else if (probe == 3) hipLaunchKernelGGL((scene_layer_frag_kernel<true, 3>), dim3(scenes), dim3(512), 0, s, *a);
+    else if (probe == 4) hipLaunchKernelGGL((scene_layer_frag_kernel<true, 4>), dim3(scenes), dim3(512), 0, s, *a);
+    else if (gn) hipLaunchKernelGGL((scene_layer_frag_kernel<true, 0>), dim3(scenes), dim3(512), 0, s, *a);
+    else hipLaunchKernelGGL((scene_layer_frag_kernel<false, 0>), dim3(scenes), dim3(512), 0, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tune_scene_direct_launch(int gn, const dsc_gemm_args* a, void* stream) {
+    const int scenes = a->m / a->tokens_per_scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = dsc_scene::SC_WP_SMEM_FLOATS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_direct_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_direct_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    if (gn) hipLaunchKernelGGL(scene_layer_direct_kernel<true>, dim3(scenes), dim3(512), lds, s, *a);
+    else hipLaunchKernelGGL(scene_layer_direct_kernel<false>, dim3(scenes), dim3(512), lds, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int tune_scene_launch(int gn, const dsc_gemm_args* a, void* stream) {
+    static bool attr = false;
+    const size_t lds = dsc_scene::SC_SMEM_FLOATS * sizeof(float);
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    const int scenes = a->m / a->tokens_per_scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gn) hipLaunchKernelGGL(scene_layer_kernel<true>, dim3(scenes), dim3(512), lds, s, *a);
+    else hipLaunchKernelGGL(scene_layer_kernel<false>, dim3(scenes), dim3(512), lds, s, *a);
+    return (int)hipGetLastError();
+}
