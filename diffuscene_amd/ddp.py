@@ -5,9 +5,10 @@ One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm
 Scenes are independent, so the batch is sharded over ranks with no data-path collective; the ONLY exchange is
 one averaged all-reduce of the 77.7 M fp32 gradients per step.  Gradients are packed into a few large
 contiguous buckets (default 128 MiB: xGMI is point-to-point, per-link bandwidth-bound, so few large
-messages beat many small ones) and the bucket all-reduces are issued asynchronously so bucket i+1 is being
-packed while bucket i is on the wire; the global-norm clip then runs on the reduced gradients, identical on
-every rank, with no extra collective.
+messages beat many small ones).  ``OverlappedGradientReducer`` launches a bucket's asynchronous all-reduce from
+gradient hooks as soon as backward has produced its last gradient, so the exchange overlaps the rest of backward;
+``average_gradients`` is the non-overlapped form (all buckets after backward).  The global-norm clip then runs on the
+reduced gradients, identical on every rank, with no extra collective.
 """
 import os
 
@@ -67,6 +68,89 @@ def clip_grad_norm_fused(parameters, max_norm):
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     torch._foreach_mul_(grads, coef)
     return total
+
+
+class OverlappedGradientReducer:
+    """All-reduce overlapped with backward: parameters are bucketed in reverse registration order (the order
+    backward produces their gradients); a post-accumulate-grad hook per parameter counts a bucket's gradients in and, when
+    the bucket is complete, packs it and launches its asynchronous all-reduce while backward keeps running on the compute
+    stream.  ``finish()`` (after ``loss.backward()``) flushes incomplete buckets (parameters that received no gradient),
+    waits for the collectives and writes the averaged gradients back.  Bucket composition is a pure function of the
+    module structure, so every rank issues the same collectives in the same order."""
+
+    def __init__(self, model, bucket_bytes=None):
+        self.ws = world()
+        self.bucket_bytes = bucket_bytes or BUCKET_BYTES
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.buckets = []
+        cur, size = [], 0
+        for p in reversed(params):
+            n = p.numel() * p.element_size()
+            if cur and size + n > self.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += n
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._pending = []
+        self.launched_during_backward = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in params]
+
+    def _hook(self, p):
+        if self.ws == 1:
+            return
+        bi = self._bucket_of[id(p)]
+        self._ready[bi] += 1
+        if self._ready[bi] == len(self.buckets[bi]) and not self._launched[bi]:
+            self._launch(bi)
+            self.launched_during_backward += 1
+
+    def _launch(self, bi):
+        ps = [p for p in self.buckets[bi] if p.grad is not None]
+        self._launched[bi] = True
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((work, flat, ps))
+
+    def finish(self):
+        """-> number of bucket all-reduces of this step."""
+        if self.ws == 1:
+            return 0
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        inv = 1.0 / self.ws
+        n = len(self._pending)
+        for work, flat, ps in self._pending:
+            work.wait()
+            flat.mul_(inv)
+            torch._foreach_copy_([p.grad for p in ps], [t.view_as(p.grad) for t, p in zip(flat.split([p.grad.numel() for p in ps]), ps)])
+        self._pending = []
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        return n
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def overlapped_reducer(model, bucket_bytes=None):
+    """The reducer attached to ``model`` (created on first use; None when not distributed)."""
+    if world() == 1 or os.environ.get("DSC_DDP_OVERLAP", "1") == "0":
+        return None
+    r = getattr(model, "_dsc_grad_reducer", None)
+    if r is None:
+        r = OverlappedGradientReducer(model, bucket_bytes)
+        object.__setattr__(model, "_dsc_grad_reducer", r)
+    return r
 
 
 def shard_batch(sample_params, rank=None, ws=None):

@@ -282,11 +282,15 @@ def train_on_batch(model, optimizer, sample_params, config):
     """reference :456-473: zero_grad, loss, backward, clip_grad_norm_(max_grad_norm), optimizer step.  All logged
     scalars are fetched with one device->host copy; under torch.distributed the gradients are averaged over the
     ranks (RCCL all-reduce over xGMI) before clipping, so every rank clips and steps identically."""
-    from ..ddp import average_gradients, clip_grad_norm_fused
+    from ..ddp import average_gradients, clip_grad_norm_fused, overlapped_reducer
     optimizer.zero_grad()
+    reducer = overlapped_reducer(model)      # None on one GPU; hooks launch bucket all-reduces during backward
     loss, loss_dict = model.get_loss(sample_params)
     loss.backward()
-    average_gradients(model)
+    if reducer is not None:
+        reducer.finish()
+    else:
+        average_gradients(model)             # no-op on one GPU; DSC_DDP_OVERLAP=0 selects this post-backward form
     if hasattr(optimizer, "clip_grad_norm_"):         # FusedAdam: norm + coefficient on the device, applied in step()
         grad_norm = optimizer.clip_grad_norm_(config["training"]["max_grad_norm"])
     else:

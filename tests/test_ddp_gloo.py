@@ -46,6 +46,25 @@ def _worker(rank, ws, port, out):
     gathered = [torch.zeros_like(flat) for _ in range(ws)]
     dist.all_gather(gathered, flat)
     assert torch.equal(gathered[0], gathered[1])               # every rank clips / steps identically
+    # overlapped form: bucket all-reduces launched from gradient hooks during backward give the same averaged gradients
+    m2 = _model()
+    red = ddp.overlapped_reducer(m2, bucket_bytes=4096)
+    assert red is ddp.overlapped_reducer(m2) and len(red.buckets) >= 3
+    for _ in range(2):                                          # two steps: state resets between steps
+        m2.zero_grad(set_to_none=True)
+        _loss(m2, shard).backward()
+        assert red.launched_during_backward >= 3                # complete buckets left before backward ended
+        assert red.finish() == len(red.buckets)
+    flat2 = torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+    ddp.clip_grad_norm_fused(m2.parameters(), 0.05)
+    flat2 = torch.cat([p.grad.reshape(-1) for p in m2.parameters()])
+    assert torch.allclose(flat2, flat, rtol=1e-6, atol=1e-9)
+    # a parameter without gradient (frozen branch) must not dead-lock the bucket schedule
+    m3 = _model()
+    m3[4].weight.requires_grad_(False)
+    red3 = ddp.OverlappedGradientReducer(m3, bucket_bytes=4096)
+    _loss(m3, shard).backward()
+    red3.finish()
     if rank == 0:
         torch.save({"grad": flat, "norm": total}, out)
     dist.destroy_process_group()
