@@ -255,11 +255,12 @@ _scratch = {}
 
 
 def scratch(device, floats):
-    """Per-device scratch for split reductions.  Kernels run in order on one stream, so one buffer is reused."""
-    t = _scratch.get(device)
+    """Scratch for split reductions, one buffer per (device, stream): kernels run in order on a stream, so it is reused."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _scratch.get(key)
     if t is None or t.numel() < floats:
         t = torch.empty(max(int(floats), 1 << 20), device=device, dtype=torch.float32)
-        _scratch[device] = t
+        _scratch[key] = t
     return t
 
 
