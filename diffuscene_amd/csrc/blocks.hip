@@ -213,66 +213,70 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Softmax attention core (mid_attn), one block per (scene, head), one thread per query token.
-// K/V of the scene in LDS (broadcast reads: every lane walks the same key), two passes over the keys
-// (row max, then exp / sum / PV) so the result is the plain softmax of the reference.
+// Softmax attention core (mid_attn), one block of 256 threads per (scene, head).  K/V of the scene are staged in LDS
+// (36-float rows, 16-byte reads); FOUR lanes share a query token, each owning 8 of the 32 head channels: a score is
+// 8 FMAs + two wave shuffles across the quad, every lane of a quad walks the same key (LDS broadcast).  Two passes over
+// the keys (row maximum, then exp / sum / PV), i.e. the plain softmax of the reference (denoise_net.py:252-258).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(192) void attention_kernel(const float* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int64_t ldq,
                                                         const float* __restrict__ k, int64_t ldk,
                                                         const float* __restrict__ v, int64_t ldv,
                                                         float* __restrict__ out, int64_t ldo, int n, float scale) {
-    __shared__ float Ks[MAXTOK * HP];
-    __shared__ float Vs[MAXTOK * HP];
+    extern __shared__ __attribute__((aligned(16))) float att_lds[];
+    float* Ks = att_lds;                  // [n][LP]
+    float* Vs = Ks + n * LP;              // [n][LP]
     const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
     const int tid = threadIdx.x;
     const float* kb = k + (int64_t)b * n * ldk + h * 32;
     const float* vb = v + (int64_t)b * n * ldv + h * 32;
-    for (int f = tid; f < n * 8; f += 192) {
+    for (int f = tid; f < n * 8; f += 256) {
         const int j = f >> 3, c4 = (f & 7) * 4;
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { Ks[j * HP + c4 + e] = kv[e]; Vs[j * HP + c4 + e] = vv[e]; }
+        *reinterpret_cast<f32x4*>(Ks + j * LP + c4) = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
+        *reinterpret_cast<f32x4*>(Vs + j * LP + c4) = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
     }
     __syncthreads();
-    const int i = tid;
-    if (i >= n) return;
-    const float* qr = q + ((int64_t)b * n + i) * ldq + h * 32;
-    float qv[32];
+    const int part = tid & 3;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + (tid >> 2);
+        const bool ok = i < n;
+        const float* qr = q + ((int64_t)b * n + (ok ? i : 0)) * ldq + h * 32 + part * 8;
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(qr), qc = *reinterpret_cast<const f32x4*>(qr + 4);
+        float qv[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(qr + c * 4);
+        for (int e = 0; e < 4; ++e) { qv[e] = qa[e] * scale; qv[4 + e] = qc[e] * scale; }
+        auto score = [&](int j) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + j * LP + part * 8);
+            const f32x4 kc = *reinterpret_cast<const f32x4*>(Ks + j * LP + part * 8 + 4);
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qv[c * 4 + e] = t4[e] * scale;
-    }
-    float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) {
-        float s = 0.f;
+            for (int e = 0; e < 4; ++e) s += qv[e] * ka[e];
 #pragma unroll
-        for (int d = 0; d < 32; ++d) s += qv[d] * Ks[j * HP + d];
-        mx = fmaxf(mx, s);
-    }
-    float o[32];
+            for (int e = 0; e < 4; ++e) s += qv[4 + e] * kc[e];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            return s;
+        };
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, score(j));
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float sm = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float pj = expf(score(j) - mx);
+            sm += pj;
+            const f32x4 va = *reinterpret_cast<const f32x4*>(Vs + j * LP + part * 8);
+            const f32x4 vc = *reinterpret_cast<const f32x4*>(Vs + j * LP + part * 8 + 4);
 #pragma unroll
-    for (int d = 0; d < 32; ++d) o[d] = 0.f;
-    float sm = 0.f;
-    for (int j = 0; j < n; ++j) {
-        float s = 0.f;
+            for (int e = 0; e < 4; ++e) { o[e] += pj * va[e]; o[4 + e] += pj * vc[e]; }
+        }
+        if (ok) {
+            const float inv = 1.0f / sm;
+            float* orow = out + ((int64_t)b * n + i) * ldo + h * 32 + part * 8;
+            f32x4 t0, t1;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) s += qv[d] * Ks[j * HP + d];
-        const float pj = expf(s - mx);
-        sm += pj;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) o[d] += pj * Vs[j * HP + d];
-    }
-    const float inv = 1.0f / sm;
-    float* orow = out + ((int64_t)b * n + i) * ldo + h * 32;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        f32x4 t4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t4[e] = o[c * 4 + e] * inv;
-        *reinterpret_cast<f32x4*>(orow + c * 4) = t4;
+            for (int e = 0; e < 4; ++e) { t0[e] = o[e] * inv; t1[e] = o[4 + e] * inv; }
+            *reinterpret_cast<f32x4*>(orow) = t0;
+            *reinterpret_cast<f32x4*>(orow + 4) = t1;
+        }
     }
 }
 
@@ -403,7 +407,7 @@ extern "C" int dsc_attention_f32(const float* q, int64_t ldq, const float* k, in
     if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(out) ||
         (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DSC_EALIGN;
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(attention_kernel, dim3(scenes * DSC_HEADS), dim3(192), 0,
+    hipLaunchKernelGGL(attention_kernel, dim3(scenes * DSC_HEADS), dim3(256), (size_t)2 * n * LP * sizeof(float),
                        static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, n, scale);
     DSC_LAUNCH_CHECK();
     return 0;

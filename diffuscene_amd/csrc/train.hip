@@ -729,6 +729,121 @@ __global__ __launch_bounds__(192) void attention_bwd_kernel(
     }
 }
 
+// Same backward for scenes of up to 96 tokens: the probabilities P and dS = P (dP - D) are kept in LDS instead of being
+// recomputed per key, and 4 lanes share a query / key (8 of the 32 head channels each, 16-byte LDS reads, quad shuffles).
+// LDS: Q (pre-scaled), K, V, dO as [n][36]; P, dS as [n][n+1].
+__global__ __launch_bounds__(256) void attention_bwd_cached_kernel(
+        const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk, const float* __restrict__ v, long ldv,
+        const float* __restrict__ dout, long ldo, float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
+        float* __restrict__ dv, long lddv, int n, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LQ = 36;
+    const int PS = n + 1;
+    float* Qs = lds;
+    float* Ks = Qs + n * LQ;
+    float* Vs = Ks + n * LQ;
+    float* DO = Vs + n * LQ;
+    float* P = DO + n * LQ;
+    float* DS = P + n * PS;
+    const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
+    const int tid = threadIdx.x, part = tid & 3;
+    for (int f = tid; f < n * 8; f += 256) {
+        const int j = f >> 3, c4 = (f & 7) * 4;
+        const long row = (long)b * n + j;
+        f32x4 qv = *reinterpret_cast<const f32x4*>(q + row * ldq + h * 32 + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[e] *= scale;
+        *reinterpret_cast<f32x4*>(Qs + j * LQ + c4) = qv;
+        *reinterpret_cast<f32x4*>(Ks + j * LQ + c4) = *reinterpret_cast<const f32x4*>(k + row * ldk + h * 32 + c4);
+        *reinterpret_cast<f32x4*>(Vs + j * LQ + c4) = *reinterpret_cast<const f32x4*>(v + row * ldv + h * 32 + c4);
+        *reinterpret_cast<f32x4*>(DO + j * LQ + c4) = *reinterpret_cast<const f32x4*>(dout + row * ldo + h * 32 + c4);
+    }
+    __syncthreads();
+    auto dot8 = [&](const float* a, const float (&x)[8]) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += x[e] * a0[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += x[4 + e] * a1[e];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        return s;
+    };
+    // phase 1: per query i -- P[i][:], D_i, dS[i][:], dq_i
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + (tid >> 2);
+        const bool ok = i < n;
+        const int ic = ok ? i : 0;
+        float qv[8], dov[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qv[e] = Qs[ic * LQ + part * 8 + e]; dov[e] = DO[ic * LQ + part * 8 + e]; }
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) {
+            const float s = dot8(Ks + j * LQ + part * 8, qv);
+            if (ok && part == 0) P[i * PS + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sm = 0.f, Dn = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float dp = dot8(Vs + j * LQ + part * 8, dov);
+            const float pj = expf((ok ? P[i * PS + j] : 0.f) - mx);      // own write (part 0) visible: same wave, in order
+            sm += pj;
+            Dn += pj * dp;
+            if (ok && part == 0) { P[i * PS + j] = pj; DS[i * PS + j] = dp; }
+        }
+        const float inv = 1.0f / sm;
+        const float Di = Dn * inv;
+        float dqv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < n; ++j) {
+            const float pij = (ok ? P[i * PS + j] : 0.f) * inv;
+            const float ds = pij * ((ok ? DS[i * PS + j] : 0.f) - Di);
+            if (ok && part == 0) { P[i * PS + j] = pij; DS[i * PS + j] = ds; }
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(Ks + j * LQ + part * 8);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(Ks + j * LQ + part * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dqv[e] += ds * k0[e]; dqv[4 + e] += ds * k1[e]; }
+        }
+        if (ok) {
+            float* o = dq + ((long)b * n + i) * lddq + h * 32 + part * 8;
+            f32x4 t0, t1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { t0[e] = dqv[e] * scale; t1[e] = dqv[4 + e] * scale; }
+            *reinterpret_cast<f32x4*>(o) = t0;
+            *reinterpret_cast<f32x4*>(o + 4) = t1;
+        }
+    }
+    __syncthreads();
+    // phase 2: per key j -- dv_j = sum_i P_ij dO_i, dk_j = sum_i dS_ij Q_i (Q already carries the scale)
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + (tid >> 2);
+        const bool ok = j < n;
+        const int jc = ok ? j : 0;
+        float dkv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dvv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < n; ++i) {
+            const float pij = P[i * PS + jc], ds = DS[i * PS + jc];
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(Qs + i * LQ + part * 8);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(Qs + i * LQ + part * 8 + 4);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(DO + i * LQ + part * 8);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(DO + i * LQ + part * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dkv[e] += ds * q0[e]; dkv[4 + e] += ds * q1[e];
+                dvv[e] += pij * d0[e]; dvv[4 + e] += pij * d1[e];
+            }
+        }
+        if (ok) {
+            float* ok_ = dk + ((long)b * n + j) * lddk + h * 32 + part * 8;
+            float* ov = dv + ((long)b * n + j) * lddv + h * 32 + part * 8;
+            f32x4 a0, a1, b0, b1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a0[e] = dkv[e]; a1[e] = dkv[4 + e]; b0[e] = dvv[e]; b1[e] = dvv[4 + e]; }
+            *reinterpret_cast<f32x4*>(ok_) = a0; *reinterpret_cast<f32x4*>(ok_ + 4) = a1;
+            *reinterpret_cast<f32x4*>(ov) = b0; *reinterpret_cast<f32x4*>(ov + 4) = b1;
+        }
+    }
+}
+
 // dx = dy * act'(x)
 __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
                                long count, int act) {
@@ -941,6 +1056,22 @@ extern "C" int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k
     if ((ldq | ldk | ldv | ldo | lddq | lddk | lddv) & 3) return DSC_EALIGN;
     if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(dout) || !dsc_aligned16(dq) ||
         !dsc_aligned16(dk) || !dsc_aligned16(dv)) return DSC_EALIGN;
+    if (n <= 96) {
+        const size_t ldc = sizeof(float) * ((size_t)4 * n * 36 + (size_t)2 * n * (n + 1));       // <= 128 KB
+        static bool attr_c = false;
+        if (!attr_c) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_cached_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_c = true;
+        }
+        DSC_CLEAR_STALE_ERROR();
+        hipLaunchKernelGGL(attention_bwd_cached_kernel, dim3(scenes * DSC_HEADS), dim3(256), ldc,
+                           static_cast<hipStream_t>(stream), q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo, dq,
+                           (long)lddq, dk, (long)lddk, dv, (long)lddv, n, scale);
+        DSC_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = sizeof(float) * ((size_t)4 * n * HP + 3 * n);
     static bool attr_set = false;
     if (!attr_set) {
