@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
         }
     }
     float* out = p.out + (long)split * p.slab;
+    const bool vec = (p.ldo & 3) == 0 && (p.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
     if (do_bias && j0 + tid < p.n) p.bias_out[(long)split * p.bias_slab + j0 + tid] = bsum;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -124,9 +125,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int i = i0 + (wi * 2 + a) * 32 + 8 * q + 4 * half;   // output column (k), 4 consecutive
+                if (vec && i + 3 < p.kvalid) {
+                    f32x4 t4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[a][b][4 * q + e];
+                    for (int e = 0; e < 4; ++e) t4[e] = acc[a][b][4 * q + e];
+                    *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = t4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[a][b][4 * q + e];
+                }
             }
     }
 }
