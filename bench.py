@@ -130,7 +130,9 @@ def roofline_dominant_kernel(plan, B, N):
     import ctypes as C
     from diffuscene_amd import _lib, ops
     fn = _lib.fn("dsc_gemm_gn_silu_f32")
-    steps = [a for f, a in plan.steps if f is fn]
+    if getattr(plan, "n_chains", 0) > 0:
+        return roofline_scene_chain(plan, B, N)
+    steps = [a for f, a in plan.tiled_steps if f is fn]
     structs = [a[0]._obj for a in steps]          # ctypes.byref(struct) keeps the struct in ._obj
     sel = [(a, s) for a, s in zip(steps, structs) if s.k1 + s.k2 == 512]
     s = ops.stream_ptr()
@@ -161,6 +163,47 @@ def roofline_dominant_kernel(plan, B, N):
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
             "launches_per_step": len(steps), "algorithmic_flops_per_launch": flops,
             "traffic": traffic, "traffic_source": traffic_src}
+
+
+def roofline_scene_chain(plan, B, N):
+    """When the plan runs whole ResnetBlocks as scene-resident chains, that kernel carries most of the FLOPs: time every
+    chain launch of the plan with HIP events on the launch stream; algorithmic FLOPs = sum over the chained layers of
+    2*M*n*K.  The tiled GN-GEMM of the one-launch-per-layer plan is timed next to it for comparison."""
+    from diffuscene_amd import _lib, ops
+    chain_f = _lib.fn("dsc_scene_chain_f32")
+    gn_f = _lib.fn("dsc_gemm_gn_silu_f32")
+    chains = [a for f, a in plan.steps if f is chain_f]
+    s = ops.stream_ptr()
+    flops, layers = 0.0, 0
+    for arr, flags, cnt, _n in chains:
+        for j in range(cnt):
+            flops += 2.0 * arr[j].m * arr[j].n * (arr[j].k1 + arr[j].k2)
+            layers += 1
+
+    def timeit(calls, f, reps=3):
+        for a in calls[:2]:
+            f(*a, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for a in calls:
+                f(*a, s)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps          # ms for one pass over `calls`
+    ms_chain = timeit(chains, chain_f)
+    achieved = flops / (ms_chain * 1e-3) / 1e12
+    tiled = [a for f, a in plan.tiled_steps if f is gn_f and a[0]._obj.k1 + a[0]._obj.k2 == 512]
+    ms_tiled = timeit(tiled, gn_f) / max(len(tiled), 1)
+    tiled_tf = 2.0 * plan.B * N * 512 * 512 / (ms_tiled * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "scene_chain_kernel (one workgroup per scene walks %d fused 512-wide layers in %d launches; "
+                                       "WS-conv+GroupNorm+SiLU / res_conv / MLP trunk layers)" % (layers, len(chains)),
+            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms_chain * 1e3 / len(chains), 2),
+            "launches_per_step": len(chains), "layers_per_step": layers, "algorithmic_flops_per_step": flops,
+            "traffic": None, "traffic_source": None,
+            "tiled_gn_gemm": {"avg_launch_us": round(ms_tiled * 1e3, 2), "achieved": round(tiled_tf, 2),
+                              "frac": round(tiled_tf / PEAK_FP32_MFMA_TFLOPS, 4)}}
 
 
 def cpu_baseline(args, mode):

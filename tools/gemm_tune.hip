@@ -113,6 +113,26 @@ extern "C" int tune_scene_probe_launch(int probe, const dsc_gemm_args* a, void* 
     return (int)hipGetLastError();
 }
 
+template <bool GN>
+__global__ __launch_bounds__(512, 1) void scene_layer_g2_kernel(const dsc_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) float scene_smem[];
+    dsc_scene::scene_gemm<GN, 4>(p, blockIdx.x, p.tokens_per_scene, scene_smem);
+}
+extern "C" int tune_scene_g2_launch(int gn, const dsc_gemm_args* a, void* stream) {
+    const size_t lds = dsc_scene::SC_G2_SMEM_FLOATS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_g2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scene_layer_g2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int scenes = a->m / a->tokens_per_scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gn) hipLaunchKernelGGL(scene_layer_g2_kernel<true>, dim3(scenes), dim3(512), lds, s, *a);
+    else hipLaunchKernelGGL(scene_layer_g2_kernel<false>, dim3(scenes), dim3(512), lds, s, *a);
+    return (int)hipGetLastError();
+}
+
 template <bool GN, int PROBE>
 __global__ __launch_bounds__(512, 1) void scene_layer_frag_kernel(const dsc_gemm_args p) {
     dsc_scene::scene_gemm<GN, 3, PROBE>(p, blockIdx.x, p.tokens_per_scene, nullptr);

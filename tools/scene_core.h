@@ -32,6 +32,7 @@ constexpr int SC_SMEM_FLOATS = 2 * SC_STAGE;                // 28416 floats = 11
 // (p.n must be 512).  All 512 threads must call this; ends with the block's stores issued (caller fences/syncs).
 constexpr int SC_WP_WAVE_FLOATS = (64 + SC_ROWS) * SC_LD;    // wave-private LDS region: 64 weight rows + 80 token rows
 constexpr int SC_WP_SMEM_FLOATS = 8 * SC_WP_WAVE_FLOATS;     // 27648 floats = 108 KB
+constexpr int SC_G2_SMEM_FLOATS = 2 * 2 * (256 + SC_ROWS) * SC_LD + 64;   // two groups x two stages + barrier counters = 126 KB
 
 // MODE 0: block-staged LDS tiles + one __syncthreads per K group; 1: fragments straight from global memory (uncoalesced
 // in lane order, TA-bound -- kept for reference); 2: wave-private LDS staging, no block barrier in the main loop.
@@ -154,6 +155,96 @@ __device__ __forceinline__ void scene_gemm(const dsc_gemm_args& p, const int sce
         mma(wfA, xfA);
         __builtin_amdgcn_sched_barrier(0);
         fetch(kg + 2 < KG ? kg + 2 : KG - 1, wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wfB, xfB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (MODE == 4) {
+    // Two independent 4-wave groups (one wave per SIMD each): group g owns channels [256g, 256g+256), stages ITS weight rows
+    // and the scene's token rows into its own double-buffered LDS tiles (coalesced loads shared by the group's 4 waves, so
+    // the bytes per MFMA match the product kernel) and synchronises with an LDS-counter barrier of its own.  The two groups
+    // drift out of phase like two independent blocks on a CU: one group's staging / barrier / fragment-read gap is covered
+    // by the other group's MFMAs.
+    constexpr int GROWS = 256 + SC_ROWS;                      // staged rows per group and K group
+    constexpr int GSTAGE = GROWS * SC_LD;                     // floats per stage
+    const int grp = wave >> 2, gw = wave & 3, gt = tid & 255;
+    float* gbase = smem + grp * (2 * GSTAGE);
+    unsigned* bar = reinterpret_cast<unsigned*>(smem + 2 * 2 * GSTAGE) + grp * 32;   // one counter per group (own bank line)
+    if (tid < 64) reinterpret_cast<unsigned*>(smem + 2 * 2 * GSTAGE)[tid] = 0u;
+    __syncthreads();
+    unsigned bar_target = 0;
+    auto group_barrier = [&]() {
+        bar_target += 4;
+        if (lane == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < bar_target)
+            __builtin_amdgcn_s_sleep(1);
+    };
+    // staging map of the group's 256 threads: 336 rows x 4 quads = 1344 quads -> 5.25 per thread
+    constexpr int NQ = GROWS * 4;
+    f32x4 st[6];
+    auto gload = [&](int kt) {
+        const int k0 = kt * SC_BK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int f = gt + 256 * i;
+            const int r = f >> 2, qd = f & 3;
+            if (i < 5 || f < NQ) {
+                if (r < 256) {
+                    const int c = grp * 256 + r;
+                    st[i] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)(c < n ? c : 0) * p.ldw + k0 + qd * 4);
+                } else {
+                    const int t = r - 256;
+                    const int64_t row = row0 + (t < N ? t : 0);
+                    st[i] = (k0 < p.k1) ? *reinterpret_cast<const f32x4*>(p.a1 + row * p.lda1 + k0 + qd * 4)
+                                        : *reinterpret_cast<const f32x4*>(p.a2 + row * p.lda2 + (k0 - p.k1) + qd * 4);
+                }
+            }
+        }
+    };
+    auto lds_put = [&](float* stage) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int f = gt + 256 * i;
+            const int r = f >> 2, qd = f & 3;
+            if (i < 5 || f < NQ) *reinterpret_cast<f32x4*>(stage + r * SC_LD + qd * 4) = st[i];
+        }
+    };
+    f32x4 wfA[4], xfA[SC_TT], wfB[4], xfB[SC_TT];
+    auto lds_get = [&](const float* stage, f32x4 (&wf)[4], f32x4 (&xf)[SC_TT]) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            wf[ct] = *reinterpret_cast<const f32x4*>(stage + (gw * 64 + ct * 16 + li) * SC_LD + lg * 4);
+#pragma unroll
+        for (int tt = 0; tt < SC_TT; ++tt)
+            xf[tt] = *reinterpret_cast<const f32x4*>(stage + (256 + tt * 16 + li) * SC_LD + lg * 4);
+    };
+    auto mma = [&](const f32x4 (&wf)[4], const f32x4 (&xf)[SC_TT]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tt = 0; tt < SC_TT; ++tt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ct][s], xf[tt][s], acc[tt][ct], 0, 0, 0);
+    };
+    // the wave -> channel map of the epilogue below expects wave w to own channels [64w, 64w+64): grp*256 + gw*64 = 64*wave
+    gload(0);
+    lds_put(gbase);
+    gload(1);
+    group_barrier();
+    lds_get(gbase, wfA, xfA);
+    for (int kt = 0; kt < nk; kt += 2) {
+        lds_put(gbase + GSTAGE);                              // group kt+1
+        gload(kt + 2 < nk ? kt + 2 : nk - 1);
+        group_barrier();
+        lds_get(gbase + GSTAGE, wfB, xfB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wfA, xfA);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_put(gbase);                                       // group kt+2
+        gload(kt + 3 < nk ? kt + 3 : nk - 1);
+        group_barrier();
+        lds_get(gbase, wfA, xfA);
         __builtin_amdgcn_sched_barrier(0);
         mma(wfB, xfB);
         __builtin_amdgcn_sched_barrier(0);

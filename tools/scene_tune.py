@@ -63,6 +63,16 @@ def main():
                 t0 = timeit(lambda: fn(C.byref(g0), s))
                 t1 = timeit(lambda: lib.tune_scene_launch(gn, C.byref(g1), s))
                 t2 = timeit(lambda: lib.tune_scene_direct_launch(gn, C.byref(g2), s))
+                y4 = torch.zeros(M, 512, device=dev)
+                g4 = ops.make_gemm_args(a, w, y4, b, a2, r, **kw)
+                g4.tokens_per_scene = N
+                lib.tune_scene_g2_launch.argtypes = [C.c_int, C.POINTER(_lib.GemmArgs), C.c_void_p]
+                rc = lib.tune_scene_g2_launch(gn, C.byref(g4), s)
+                torch.cuda.synchronize()
+                assert rc == 0, rc
+                err4 = float((y4 - y0).abs().max() / y0.abs().max())
+                t4 = timeit(lambda: lib.tune_scene_g2_launch(gn, C.byref(g4), s))
+                print("      two 4-wave groups, LDS-counter barriers: %7.1f us (%5.1f TF) err %.1e" % (t4, 2.0 * M * 512 * K / 1e6 / t4, err4))
                 # fragment-major operands (N == 80 only): swizzle on the host side of the test
                 if N == 80:
                     def frag_x(x):          # [M, Kc] -> [scene][tt][kg][lg][li][4]
