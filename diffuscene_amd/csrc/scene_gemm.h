@@ -139,6 +139,19 @@ __device__ __forceinline__ void scene_gemm(const dsc_gemm_args& p, const int sce
   }
     // ---------------------------------------------------------------- epilogue (lane: token li + 16 tt, 4 channels)
     const int cbase = wave * 64 + lg * 4;                    // + 16 ct
+    // residual quads are requested now, ahead of the statistics, into registers the main loop no longer needs
+    const bool res_pre = p.residual && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.residual) & 15) == 0 && n == 512;
+    f32x4 rpre[SC_TT][4];
+    if (res_pre) {
+#pragma unroll
+        for (int tt = 0; tt < SC_TT; ++tt) {
+            const int tl = li + 16 * tt;
+            const int64_t tok = row0 + (tl < N ? tl : 0);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                rpre[tt][ct] = *reinterpret_cast<const f32x4*>(p.residual + tok * p.ldr + cbase + 16 * ct);
+        }
+    }
     if (p.bias) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
@@ -214,7 +227,10 @@ __device__ __forceinline__ void scene_gemm(const dsc_gemm_args& p, const int sce
                     for (int e = 0; e < 4; ++e) v[e] = dsc_silu(v[e]);
                 }
             }
-            if (p.residual) {
+            if (res_pre) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rpre[tt][ct][e];
+            } else if (p.residual) {
                 if (res_vec && c + 3 < n) {
                     const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.residual + tok * p.ldr + c);
 #pragma unroll

@@ -72,7 +72,7 @@ class Plan:
     def _chains_enabled(self):
         """Runs of consecutive 512-wide GEMM layers (a whole ResnetBlock, the MLP trunks) can run as ONE launch in which
         every workgroup owns a scene (csrc/scene_chain.hip), selected with DSC_SCENE_CHAIN=1.  Measured at B=256, N=80:
-        the chained layers run at 106.9 TFLOP/s vs 104.6 for the tiled GN-GEMM, but the whole step is 12.56 ms vs 12.22 ms
+        the chained layers run at 108.9 TFLOP/s vs 104.6 for the tiled GN-GEMM, but the whole step is 12.40 ms vs 12.22 ms
         (the K=1024 layers lose to the 8-wave tiled kernel and a single resident block still exposes every layer's
         epilogue), so the one-launch-per-layer plan stays the default."""
         import os
