@@ -1,93 +1,111 @@
-"""Training statistics logger -- same interface as scene_synthesis/stats_logger.py (StatsLogger singleton with
-running means, optional WandB subclass); ``wandb`` is imported lazily because it is an optional dependency."""
+"""Running-mean statistics for the training loop, keyed by name.
+
+Public surface used by the scripts and by train_on_batch / validate_on_batch (scene_synthesis/stats_logger.py):
+``StatsLogger.instance()`` (process-wide singleton), ``logger[name].value = x`` (feed a sample; reading ``.value`` gives the
+mean since the last ``clear()``), ``add_output_file``, ``print_progress(epoch, batch, loss)``, ``clear()``; ``WandB`` is the
+same logger that also ships the means to Weights & Biases (``wandb`` is imported only when that class is used).
+"""
 import sys
 
 
-class AverageAggregator(object):
-    def __init__(self):
-        self._value = 0
-        self._count = 0
+class _RunningMean:
+    """``m.value = x`` accumulates, ``m.value`` reads the mean of everything fed so far."""
 
-    @property
-    def value(self):
-        return self._value / self._count
-
-    @value.setter
-    def value(self, val):
-        self._value += val
-        self._count += 1
-
-
-class StatsLogger(object):
-    __INSTANCE = None
+    __slots__ = ("total", "n")
 
     def __init__(self):
-        if StatsLogger.__INSTANCE is not None:
+        self.total, self.n = 0.0, 0
+
+    def _get(self):
+        return self.total / self.n
+
+    def _feed(self, x):
+        self.total += x
+        self.n += 1
+
+    value = property(_get, _feed)
+
+
+AverageAggregator = _RunningMean          # name exported by the reference module
+
+
+class StatsLogger:
+    _singleton = None
+
+    def __init__(self):
+        if type(self)._shared() is not None:
             raise RuntimeError("StatsLogger should not be directly created")
-        self._values = dict()
-        self._loss = AverageAggregator()
-        self._output_files = [sys.stdout]
+        self._means = {}
+        self._loss = _RunningMean()
+        self._sinks = [sys.stdout]
 
-    def add_output_file(self, f):
-        self._output_files.append(f)
-
-    def __getitem__(self, key):
-        if key not in self._values:
-            self._values[key] = AverageAggregator()
-        return self._values[key]
-
-    def clear(self):
-        self._values.clear()
-        self._loss = AverageAggregator()
-        for f in self._output_files:
-            if f.isatty():
-                print(file=f, flush=True)
-
-    def print_progress(self, epoch, batch, loss, precision="{:.5f}"):
-        self._loss.value = loss
-        msg = ("epoch: {} - batch: {} - loss: " + precision).format(epoch, batch, self._loss.value)
-        for k, v in self._values.items():
-            msg += " - " + k + ": " + precision.format(v.value)
-        for f in self._output_files:
-            if f.isatty():
-                print(msg + "\b" * len(msg), end="", flush=True, file=f)
-            else:
-                print(msg, flush=True, file=f)
+    # -- singleton ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _shared():
+        return StatsLogger._singleton
 
     @classmethod
     def instance(cls):
-        if StatsLogger.__INSTANCE is None:
-            StatsLogger.__INSTANCE = cls()
-        return StatsLogger.__INSTANCE
+        if StatsLogger._singleton is None:
+            StatsLogger._singleton = cls()
+        return StatsLogger._singleton
+
+    # -- feeding / reading ---------------------------------------------------------------------------------------
+    def __getitem__(self, name):
+        return self._means.setdefault(name, _RunningMean())
+
+    def add_output_file(self, f):
+        self._sinks.append(f)
+
+    def _line(self, epoch, batch, precision):
+        parts = ["epoch: %s" % epoch, "batch: %s" % batch, "loss: " + precision.format(self._loss.value)]
+        parts += ["%s: %s" % (k, precision.format(m.value)) for k, m in self._means.items()]
+        return " - ".join(parts)
+
+    def print_progress(self, epoch, batch, loss, precision="{:.5f}"):
+        self._loss.value = loss
+        text = self._line(epoch, batch, precision)
+        for sink in self._sinks:
+            if sink.isatty():                       # terminals: rewrite the same line
+                sink.write(text + "\b" * len(text))
+            else:
+                sink.write(text + "\n")
+            sink.flush()
+
+    def clear(self):
+        self._means = {}
+        self._loss = _RunningMean()
+        for sink in self._sinks:
+            if sink.isatty():
+                sink.write("\n")
+                sink.flush()
 
 
 class WandB(StatsLogger):
-    """StatsLogger that also sends the running means to Weights & Biases when cleared (interface of the
-    reference stats_logger.py:67-125: ``init(experiment_arguments, model, project, name, watch, log_frequency)``,
-    validation values get a ``val_`` prefix when ``print_progress`` is called with a negative epoch)."""
+    """Ships the means of every interval to Weights & Biases on ``clear()``; intervals whose ``print_progress`` calls used a
+    negative epoch are validation intervals and get a ``val_`` prefix (reference stats_logger.py:67-125)."""
 
     def init(self, experiment_arguments, model, project="experiment", name="experiment_name", watch=True,
              log_frequency=10):
         import wandb
-        self.project, self.experiment_name = project, name
-        self.watch, self.log_frequency = watch, log_frequency
-        self._epoch, self._validation = 0, False
+        self.project, self.experiment_name, self.watch, self.log_frequency = project, name, watch, log_frequency
+        self._last_epoch, self._in_validation = 0, False
         wandb.login()
-        wandb.init(project=(project or None), name=(name or None), config=dict(experiment_arguments.items()))
+        wandb.init(project=project or None, name=name or None, config=dict(experiment_arguments.items()))
         if watch:
             wandb.watch(model, log_freq=log_frequency)
 
     def print_progress(self, epoch, batch, loss, precision="{:.5f}"):
-        super().print_progress(epoch, batch, loss, precision)
-        self._validation = epoch < 0
-        if not self._validation:
-            self._epoch = epoch
+        StatsLogger.print_progress(self, epoch, batch, loss, precision)
+        self._in_validation = epoch < 0
+        if epoch >= 0:
+            self._last_epoch = epoch
 
     def clear(self):
         import wandb
-        prefix = "val_" if getattr(self, "_validation", False) else ""
-        values = {prefix + k: v.value for k, v in self._values.items()}
-        values[prefix + "loss"] = self._loss.value
-        values[prefix + "epoch"] = getattr(self, "_epoch", 0)
-        wandb.log(values)
-        super().clear()
+        tag = "val_" if getattr(self, "_in_validation", False) else ""
+        payload = {tag + k: m.value for k, m in self._means.items()}
+        payload[tag + "loss"] = self._loss.value
+        payload[tag + "epoch"] = getattr(self, "_last_epoch", 0)
+        wandb.log(payload)
+        StatsLogger.clear(self)
