@@ -21,11 +21,15 @@
 #include <type_traits>
 #include "dsc_common.h"
 
-#ifdef DSC_GEMM_TIMING          // tools/gemm_tune.hip only: per-block phase timestamps (shader clock)
+#ifdef DSC_GEMM_TIMING          // tools/gemm_tune.hip only: per-block phase timestamps (shader clock), start stagger
 extern __device__ long long g_dsc_timing[];
+extern __device__ int g_dsc_stagger;      // cycles by which the second resident block of every CU starts late
 #define DSC_STAMP(i) do { if (threadIdx.x == 0) g_dsc_timing[(blockIdx.x & 4095) * 8 + (i)] = clock64(); } while (0)
+#define DSC_STAGGER() do { if (g_dsc_stagger > 0 && blockIdx.x >= gridDim.x / 2) {                               \
+        const long long t0__ = clock64(); while (clock64() - t0__ < g_dsc_stagger) __builtin_amdgcn_s_sleep(8); } } while (0)
 #else
 #define DSC_STAMP(i) do {} while (0)
+#define DSC_STAGGER() do {} while (0)
 #endif
 
 namespace dsc_gemm {
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         g_dsc_timing[(blockIdx.x & 4095) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
     }
 #endif
+    DSC_STAGGER();
     DSC_STAMP(0);
     load_tile(0);
     if constexpr (PIPE) {
@@ -193,31 +198,45 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         store_tile(smem);
         __syncthreads();
         DSC_STAMP(1);
-        if (nk > 1) load_tile(1);
+        // branch-free, schedule-pinned pipeline: the compiler otherwise sinks the prefetches next to their uses and waits on
+        // them immediately (seen in the ISA); clamped tile indices make the last iterations re-stage the final tile
+        load_tile(nk > 1 ? 1 : 0);
         frags(smem, 0, xfA, wfA);
         for (int kt = 0; kt < nk; ++kt) {
             const float* cur = smem + (kt & 1) * STAGE;
             float* nxt = smem + ((kt + 1) & 1) * STAGE;
             if constexpr (S == 4) {
                 frags(cur, 1, xfB, wfB);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(xfA, wfA);
+                __builtin_amdgcn_sched_barrier(0);
                 frags(cur, 2, xfA, wfA);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(xfB, wfB);
+                __builtin_amdgcn_sched_barrier(0);
                 frags(cur, 3, xfB, wfB);
-                if (kt + 1 < nk) store_tile(nxt);
+                store_tile(nxt);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(xfA, wfA);
+                __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
-                if (kt + 2 < nk) load_tile(kt + 2);
-                if (kt + 1 < nk) frags(nxt, 0, xfA, wfA);
+                load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
+                frags(nxt, 0, xfA, wfA);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(xfB, wfB);
+                __builtin_amdgcn_sched_barrier(0);
             } else {
                 frags(cur, 1, xfB, wfB);
-                if (kt + 1 < nk) store_tile(nxt);
+                store_tile(nxt);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(xfA, wfA);
+                __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
-                if (kt + 2 < nk) load_tile(kt + 2);
-                if (kt + 1 < nk) frags(nxt, 0, xfA, wfA);
+                load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
+                frags(nxt, 0, xfA, wfA);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(xfB, wfB);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();

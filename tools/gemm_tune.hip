@@ -4,6 +4,8 @@
 #include "../diffuscene_amd/csrc/gemm_core.h"
 
 __device__ long long g_dsc_timing[4096 * 8];
+__device__ int g_dsc_stagger = 0;
+extern "C" int tune_set_stagger(int cycles) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dsc_stagger), &cycles, sizeof(int)); }
 
 extern "C" int tune_read_timing(long long* host, int nblocks) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dsc_timing), sizeof(long long) * 8 * nblocks);

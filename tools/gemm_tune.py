@@ -30,6 +30,13 @@ def main():
         if a_.startswith("--only="):
             only = [int(x) for x in a_[7:].split(",")]
     nores = "--nores" in sys.argv
+    stag = 0
+    for a_ in sys.argv[1:]:
+        if a_.startswith("--stagger="):
+            stag = int(a_[10:])
+    if stag:
+        lib.tune_set_stagger(stag)
+        print("stagger: second resident block starts %d cycles late" % stag)
     NV = 25
     B, N = 256, 80
     M = B * N
