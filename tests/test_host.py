@@ -160,3 +160,28 @@ def test_install_as_scene_synthesis():
         for k in [k for k in sys.modules if k.startswith("scene_synthesis")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_fused_adam_is_a_torch_adam_with_the_same_checkpoint_format():
+    """optimizer_factory returns FusedAdam: same param_groups keys / state_dict layout as torch.optim.Adam (opt_XXXXX
+    checkpoints interchangeable); stepping CPU parameters is refused (no CPU fallback)."""
+    import pytest
+    from diffuscene_amd.networks import optimizer_factory
+    from diffuscene_amd.optim import FusedAdam
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))]
+    opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4}, ps)
+    assert isinstance(opt, FusedAdam) and isinstance(opt, torch.optim.Adam)
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))], lr=2e-4,
+                           weight_decay=0.0)
+    assert set(opt.param_groups[0].keys()) == set(ref.param_groups[0].keys())
+    assert opt.param_groups[0]["lr"] == 2e-4 and opt.param_groups[0]["weight_decay"] == 0.0
+    sd, rsd = opt.state_dict(), ref.state_dict()
+    assert sd["state"] == {} and sd["param_groups"][0]["params"] == rsd["param_groups"][0]["params"]
+    ref.load_state_dict(sd)
+    opt.load_state_dict(rsd)
+    ps[0].grad = torch.ones(3, 4)
+    with pytest.raises(RuntimeError):
+        opt.step()
+    with pytest.raises(NotImplementedError):
+        FusedAdam(ps, amsgrad=True)
+    assert isinstance(optimizer_factory({"optimizer": "SGD"}, ps), torch.optim.SGD)
