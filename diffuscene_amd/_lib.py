@@ -102,6 +102,7 @@ SIGNATURES = {
     "dsc_ddpm_loss_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float),
                                     c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_void_p]),
     "dsc_activation_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
+    "dsc_transpose_batched_f32": (C.c_int, [C.POINTER(WsItem), C.c_int32, C.c_void_p]),
     "dsc_transpose_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_complete_overwrite_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_int32, C.c_void_p]),

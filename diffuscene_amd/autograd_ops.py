@@ -131,7 +131,8 @@ class ConvGnSiluFn(Function):
     """Block.forward: y = SiLU(GroupNorm8([a|a2] @ w_std.T + bias) * (scale+1) + shift) (+ residual)"""
 
     @staticmethod
-    def forward(ctx, a, w_std, bias, gamma, beta, a2, ss, residual, n_tok, ss_mode):
+    def forward(ctx, a, w_std, bias, gamma, beta, a2, ss, residual, n_tok, ss_mode, w_std_t=None):
+        ctx.w_std_t = w_std_t          # optional pre-transposed weight (K, 512): all layers transposed in one launch
         z = torch.empty((a.shape[0], w_std.shape[0]), device=a.device, dtype=torch.float32)
         y = ops.gemm_gn_silu(a, w_std, bias, gamma, beta, n_tok, a2=a2, scale_shift=ss,
                              ss_mode=ss_mode if ss is not None else SS_NONE, residual=residual, preact=z)
@@ -151,11 +152,11 @@ class ConvGnSiluFn(Function):
         k1 = a.shape[1]
         da = da2 = None
         if ctx.needs_input_grad[0] or (a2 is not None and ctx.needs_input_grad[5]):
-            d_in = ops.gemm(dz, ops.transpose(w_std))
+            d_in = ops.gemm(dz, ctx.w_std_t if ctx.w_std_t is not None else ops.transpose(w_std))
             da = d_in[:, :k1] if a2 is not None else d_in
             da2 = d_in[:, k1:] if a2 is not None else None
         dw = ops.gemm_tn(a, dz, a2=a2)
-        return da, dw, dbias, dgamma, dbeta, da2, dss, (dy if ctx.has_res else None), None, None
+        return da, dw, dbias, dgamma, dbeta, da2, dss, (dy if ctx.has_res else None), None, None, None
 
 
 class LayerNormFn(Function):
@@ -248,6 +249,9 @@ def unet1d_train_forward(net, x, t, context, context_cross):
     ws_mods = eng.ws_mods
     ws_list = WeightStandardizeAllFn.apply(*[m.weight for m in ws_mods])
     ws = {id(m): w for m, w in zip(ws_mods, ws_list)}
+    # W^T of every standardised weight for the dA GEMMs of the backward: one launch instead of one per layer
+    ws_t = {id(m): t for m, t in zip(ws_mods, ops.transpose_many([as2d(w.detach()) for w in ws_list]))} \
+        if torch.is_grad_enabled() else {}
 
     # conditioning
     temb = ops.time_embedding(t, D, eng.time_table, eng.time_freq)
@@ -281,10 +285,10 @@ def unet1d_train_forward(net, x, t, context, context_cross):
         if ss is not None:
             ss = ss.contiguous() if ss.data_ptr() % 16 or ss.stride(0) % 4 else ss
         h = ConvGnSiluFn.apply(a, ws[id(rb.block1.proj)], rb.block1.proj.bias, rb.block1.norm.weight,
-                               rb.block1.norm.bias, a2, ss, None, N, mode)
+                               rb.block1.norm.bias, a2, ss, None, N, mode, ws_t.get(id(rb.block1.proj)))
         r = LinearFn.apply(a, rb.res_conv.weight, rb.res_conv.bias, a2, None) if rb.has_res_conv else a
         return ConvGnSiluFn.apply(h, ws[id(rb.block2.proj)], rb.block2.proj.bias, rb.block2.norm.weight,
-                                  rb.block2.norm.bias, None, None, r, N, SS_NONE)
+                                  rb.block2.norm.bias, None, None, r, N, SS_NONE, ws_t.get(id(rb.block2.proj)))
 
     def linattn(blk, a):
         att = blk.fn.fn

@@ -996,6 +996,23 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
         if (c0 + c < cols && r0 + tx < rows) out[(long)(c0 + c) * ldo + r0 + tx] = tile[tx][c];
 }
 
+// batched form: one launch transposes every matrix of a list (blockIdx.z = matrix); the training backward needs W^T of all
+// 56 standardised conv weights, produced right after the standardisation instead of one launch per layer
+struct TransposeBatch { dsc_ws_item it[DSC_WS_MAX]; };
+
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const TransposeBatch bch) {
+    __shared__ float tile[32][33];
+    const dsc_ws_item it = bch.it[blockIdx.z];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (c0 >= it.cols || r0 >= it.rows) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < it.rows && c0 + tx < it.cols) tile[r][tx] = it.w[(long)(r0 + r) * it.cols + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < it.cols && r0 + tx < it.rows) it.out[(long)(c0 + c) * it.rows + r0 + tx] = tile[tx][c];
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------------- C ABI
@@ -1235,6 +1252,23 @@ extern "C" int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
                        static_cast<hipStream_t>(stream), in, (long)ldi, out, (long)ldo, rows, cols);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_transpose_batched_f32(const dsc_ws_item* items, int32_t count, dsc_stream_t stream) {
+    if (!items || count < 1 || count > DSC_WS_MAX) return DSC_EINVAL;
+    TransposeBatch b;
+    int maxr = 0, maxc = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].w || !items[i].out || items[i].rows < 1 || items[i].cols < 1) return DSC_EINVAL;
+        b.it[i] = items[i];
+        if (items[i].rows > maxr) maxr = items[i].rows;
+        if (items[i].cols > maxc) maxc = items[i].cols;
+    }
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((maxc + 31) / 32, (maxr + 31) / 32, count), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), b);
     DSC_LAUNCH_CHECK();
     return 0;
 }

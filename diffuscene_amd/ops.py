@@ -274,6 +274,21 @@ def transpose(w, out=None, ldo=None):
     return out
 
 
+def transpose_many(mats):
+    """[w_i (rows_i, cols_i)] -> [w_i^T], one launch per DSC_WS_MAX matrices."""
+    outs = [torch.empty((m.shape[1], m.shape[0]), device=m.device, dtype=torch.float32) for m in mats]
+    for i in range(0, len(mats), _lib.WS_MAX):
+        ms, os_ = mats[i:i + _lib.WS_MAX], outs[i:i + _lib.WS_MAX]
+        arr = (_lib.WsItem * len(ms))()
+        for j, (m, o) in enumerate(zip(ms, os_)):
+            if not (_dev(m).is_contiguous() and m.dim() == 2):
+                raise RuntimeError("transpose_many needs contiguous 2-D matrices")
+            arr[j].w, arr[j].out = m.data_ptr(), o.data_ptr()
+            arr[j].rows, arr[j].cols = m.shape
+        _lib.check(_lib.fn("dsc_transpose_batched_f32")(arr, len(ms), stream_ptr()), "dsc_transpose_batched_f32")
+    return outs
+
+
 def gemm_tn(a, dy, a2=None, kvalid=None, out=None, want_bias=False):
     """out[n][k] = sum_m dy[m][n] * [a|a2][m][k]  (+ column sums of dy when want_bias) -> out or (out, dbias)"""
     ap, lda = _mat(a, "a")

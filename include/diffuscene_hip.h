@@ -223,6 +223,8 @@ int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx, int64_t c
 /* out[c][r] = in[r][c] */
 int dsc_transpose_f32(const float* in, int64_t ldi, float* out, int64_t ldo, int32_t rows, int32_t cols,
                       dsc_stream_t stream);
+/* the same for up to DSC_WS_MAX contiguous matrices in one launch: items[i].out[c][r] = items[i].w[r][c] */
+int dsc_transpose_batched_f32(const dsc_ws_item* items, int32_t count, dsc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shape retrieval: nearest database object of the same class in the 32-d latent shape-code space,
