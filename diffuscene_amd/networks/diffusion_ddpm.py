@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .loss import axis_aligned_bbox_overlaps_3d
+from .loss import axis_aligned_bbox_overlaps_3d  # noqa: F401  (re-exported: the reference module exposes it, :16)
 
 ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
 

@@ -5,7 +5,6 @@ diffusion_scene_layout_ddpm.py:465 and torch.optim.Adam from networks/__init__.p
 ``opt_XXXXX`` checkpoints are interchangeable with the reference's), but ``step()`` runs csrc/optim.hip: one sweep for the
 global gradient norm, a device-side clip coefficient, one Adam sweep -- no host synchronisation, ~32 B/parameter of traffic.
 """
-import ctypes as C
 
 import numpy as np
 import torch

@@ -2,7 +2,6 @@
 (SURVEY.md 8f-3).  Mirrors ``ThreedFutureDataset.get_closest_furniture_to_objfeats`` and
 ``..._to_objfeats_and_size`` (scene_synthesis/datasets/threed_future_dataset.py:49-77) and adds the batched form a
 B>1 generation needs: all boxes of all scenes in one launch instead of a Python loop over the object list per box."""
-import ctypes as C
 
 import numpy as np
 import torch

@@ -3,7 +3,6 @@
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 from oracle import retrieval_ref as RR
 from diffuscene_amd.retrieval import ShapeCodeIndex
