@@ -1,31 +1,40 @@
 #!/usr/bin/env python
 """Benchmark of the DiffuScene DDPM hot path on MI355X (contract: see the task brief / DESIGN.md section 6).
 
-    python bench.py --gpus N --steps K --warmup W [--mode both|sample|train] [--batch 256] [--objects 80]
+    python bench.py --gpus N --steps K --warmup W [--config living80|bedroom21|text|complete|arrange]
+                    [--mode both|sample|train] [--no-cpu-baseline] [--no-full-loop]
 
-Workload (BASELINE.json `metric`): uncond living/dining rooms scaled to N=80 objects, B=256 scenes per GPU,
-C=65 channels, fp32, synthetic scenes with the real encoders' value distribution, random-init weights.
-  mode=sample : a step = one reverse-diffusion denoiser step (Unet1D forward + fused posterior step) of a
-                1000-step p_sample_loop, replayed from the captured hipGraph.
+Workloads = the five BASELINE.json configs (`--config`, default = the headline one):
+  living80   uncond living/dining rooms scaled to N=80, B=256 scenes per GPU, C=65            (BASELINE configs[2], metric)
+  bedroom21  uncond bedrooms scaled to N=21, B=256, C=62                                       (configs[1])
+  text       text-conditioned bedrooms, B=128, N=12, L=32 cross-attention tokens               (configs[3])
+  complete   scene completion (masked p_sample_loop), living N=80, B=128, P=20 given objects   (configs[4])
+  arrange    re-arrangement (5-channel model, 512-d instance+arrange condition), N=80, B=128   (configs[4])
+All fp32, synthetic scenes with the real encoders' value distribution, random-init weights.
+  mode=sample : a step = one reverse-diffusion denoiser step (Unet1D forward + fused posterior step, plus the in-painting
+                overwrite for `complete`) of a 1000-step loop, replayed from the captured hipGraph.
   mode=train  : a step = train_on_batch semantics (q_sample, forward, loss incl. IoU, backward, clip(10), Adam).
   mode=both   : (default, BASELINE.json metric "train + 1000-step sample") the K timed denoiser steps are ceil(K/2)
                 sampling steps followed by floor(K/2) training steps inside ONE timed region; the two rates are also
-                reported separately ("sample", "train").
-N > 1: one process per GPU (torchrun), batch sharded by rank (weak scaling: per-GPU batch fixed); sampling
-needs no collective, training all-reduces the gradients over RCCL.
-Prints ONE JSON line on rank 0.
+                reported separately ("sample", "train").  `full_loop` adds the wall time of one whole 1000-step
+                p_sample_loop(graph=True) (outside the timed region).
+N > 1: one process per GPU; `python bench.py --gpus N` spawns the ranks itself (torch.distributed.run, 127.0.0.1) when it
+is not already running under torchrun.  Batch sharded by rank (weak scaling: per-GPU batch fixed); sampling needs no
+collective, training all-reduces the flat gradient buffer over RCCL.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 _T0 = time.perf_counter()
@@ -36,36 +45,84 @@ def log(msg):
         print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
-def unet_forward_flops(B, N):
-    """F(B,N) = B*N*(65.01e6 + 512*N) + B*90.2e6 (uncond, C=62/65)."""
-    return B * N * (65.01e6 + 512.0 * N) + B * 90.2e6
+# ------------------------------------------------------------------------------------------ workloads
+CONFIGS = {
+    "living80": dict(batch=256, objects=80, kw="UNCOND_LIVING", class_dim=25, kind="uncond",
+                     yaml="config/uncond/diffusion_livingrooms_instancond_lat32_v.yaml scaled to N=80",
+                     title="uncond living/dining rooms"),
+    "bedroom21": dict(batch=256, objects=21, kw="UNCOND_BEDROOM", class_dim=22, kind="uncond",
+                      yaml="config/uncond/diffusion_bedrooms_instancond_lat32_v.yaml scaled to N=21",
+                      title="uncond bedrooms"),
+    "text": dict(batch=128, objects=12, kw="TEXT_BEDROOM", class_dim=22, kind="text", text_len=32,
+                 yaml="config/text/diffusion_bedrooms_instancond_lat32_v_bert.yaml (cached BERT features, L=32)",
+                 title="text-conditioned bedrooms"),
+    "complete": dict(batch=128, objects=80, kw="UNCOND_LIVING", class_dim=25, kind="complete", partial=20,
+                     yaml="config/uncond/diffusion_livingrooms_instancond_lat32_v.yaml scaled to N=80, "
+                          "p_sample_loop_complete with 20 given objects",
+                     title="scene completion, living rooms"),
+    "arrange": dict(batch=128, objects=80, kw="REARRANGE_LIVING", class_dim=25, kind="arrange",
+                    yaml="config/rearrange/diffusion_livingrooms_instancond_lat32_v_rearrange.yaml scaled to N=80",
+                    title="scene re-arrangement, living rooms"),
+}
 
 
-def build_model(args, device):
+def forward_flops(kind, B, N, L=0):
+    """Algorithmic FLOPs of one Unet1D forward (FlopCounterMode probes of the reference)."""
+    if kind == "arrange":
+        return B * N * (58.86e6 + 512.0 * N) + B * 90.2e6          # 6.147e11 @ (128, 80), 1.698e11 @ (128, 21)
+    f = B * N * (65.01e6 + 512.0 * N) + B * 90.2e6                   # uncond, C=62/65
+    if kind == "text":
+        f += 2.43e6 * B * N + 2.43e6 * B * L                         # 9 cross-attention layers
+    return f
+
+
+def build_model(spec, device):
+    import torch
     from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
     from oracle import weights as W
-    import tempfile
     stats = os.path.join(tempfile.mkdtemp(), "dataset_stats.txt")
     with open(stats, "w") as f:
         json.dump(W.DATASET_STATS, f)
-    kw = dict(W.UNCOND_LIVING)
-    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 65, "latent_dim": 0,
-           "room_mask_condition": False, "sample_num_points": args.objects, "objectness_dim": 0, "objfeat_dim": 32,
-           "class_dim": 25, "angle_dim": 2, "learnable_embedding": True, "instance_condition": True,
+    kw = dict(getattr(W, spec["kw"]))
+    nc = spec["class_dim"]
+    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 8 + nc + 32, "latent_dim": 0,
+           "room_mask_condition": False, "sample_num_points": spec["objects"], "objectness_dim": 0, "objfeat_dim": 32,
+           "class_dim": nc, "angle_dim": 2, "learnable_embedding": True, "instance_condition": True,
            "instance_emb_dim": 128,
            "diffusion_kwargs": dict(schedule_type="linear", beta_start=1e-4, beta_end=0.02, time_num=1000,
                                     loss_type="mse", model_mean_type="v", model_var_type="fixedsmall",
                                     loss_separate=True, loss_iou=True, train_stats_file=stats),
            "net_kwargs": kw}
+    if spec["kind"] == "text":
+        # BERT weights cannot be downloaded here: the model consumes cached last_hidden_state features (B, L, 768), the
+        # trainable fc_text_f (768 -> 512) stays inside the step (diffusion_scene_layout_ddpm.py:210-221)
+        cfg.update(text_condition=True, text_embed_dim=512, text_bert_cached=True)
+    if spec["kind"] == "arrange":
+        cfg.update(room_arrange_condition=True, arrange_emb_dim=384)
     torch.manual_seed(0)
-    import contextlib
-    import io
     with contextlib.redirect_stdout(io.StringIO()):
-        model = DiffusionSceneLayout_DDPM(26, None, cfg)
+        model = DiffusionSceneLayout_DDPM(nc + 1, None, cfg)
     return model.to(device), cfg
 
 
+def synth_batch(spec, device, seed):
+    import torch
+    from oracle import weights as W
+    B, N, nc = spec["batch"], spec["objects"], spec["class_dim"]
+    x = W.synth_scene_batch(B, N, nc, 32, seed=seed).to(device)
+    sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
+              "angles": x[:, :, 6:8].contiguous(), "class_labels": x[:, :, 8:8 + nc].contiguous(),
+              "objfeats_32": x[:, :, 8 + nc:].contiguous(), "room_layout": torch.zeros(B, 1, 64, 64, device=device)}
+    if spec["kind"] == "text":
+        g = torch.Generator().manual_seed(seed)
+        sample["desc_bert"] = torch.randn(B, spec["text_len"], 768, generator=g).to(device)
+        sample["description"] = ["synthetic"] * B
+    return x, sample
+
+
 def barrier(ws):
+    import torch
+    import torch.distributed as dist
     if ws > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -74,37 +131,60 @@ def barrier(ws):
 class SampleRunner:
     """Reverse-diffusion steps replayed from the captured hipGraph (sampler._StepGraph)."""
 
-    def __init__(self, args, model, device):
+    def __init__(self, spec, model, device, seed):
+        import torch
         from diffuscene_amd.sampler import _StepGraph
-        B, N, C = args.batch, args.objects, 65
-        cond = model._instance_condition(B, device)
+        B, N = spec["batch"], spec["objects"]
+        kind = spec["kind"]
+        x, sample = synth_batch(spec, device, seed)
+        C = x.shape[-1]
+        self.partial = None
         with torch.no_grad():
-            self.g = _StepGraph(model.diffusion.diffusion, model.diffusion.model, (B, N, C), device, cond, None, True)
+            cond = model._instance_condition(B, device)
+            cross, pshape = None, None
+            if kind == "text":
+                cross = model._text_condition(sample["description"], None, device, desc_bert=sample["desc_bert"])
+            if kind == "arrange":
+                cond = torch.cat([cond, model.fc_arrange_condition(model._arrange_input(x))], dim=-1).contiguous()
+                C = model.translation_dim + model.angle_dim
+            if kind == "complete":
+                self.partial = x[:, :spec["partial"], :].contiguous()
+                pshape = tuple(self.partial.shape)
+            self.shape = (B, N, C)
+            self.g = _StepGraph(model.diffusion.diffusion, model.diffusion.model, self.shape, device, cond, cross, True,
+                                partial_shape=pshape)
         log("graph captured")
-        self.g.x.normal_()
-        self.g.t.fill_(999)
+        self.reset()
 
     def run(self, n):
         for _ in range(n):
             self.g.graph.replay()
 
     def reset(self):
+        self.g.x.normal_()
         self.g.t.fill_(999)
+        if self.partial is not None:
+            self.g.partial.copy_(self.partial)
+
+    def full_loop(self):
+        """wall time of one whole 1000-step reverse loop through the graph path (x_T draw + 1000 replays + result copy)."""
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x_T = torch.randn(self.shape, device=self.g.x.device)
+        out = self.g.run(x_T, 1000, partial=self.partial)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(out).all()), "full loop produced non-finite values"
+        return dt
 
 
 class TrainRunner:
     """train_on_batch on a fixed synthetic batch (per-rank shard of the global batch)."""
 
-    def __init__(self, args, model, device, ws):
+    def __init__(self, spec, model, device, rank):
         from diffuscene_amd.networks import optimizer_factory
-        from oracle import weights as W
-        B, N = args.batch, args.objects
-        rank = dist.get_rank() if ws > 1 else 0
-        x = W.synth_scene_batch(B, N, 25, 32, seed=100 + rank).to(device)
-        self.sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
-                       "angles": x[:, :, 6:8].contiguous(), "class_labels": x[:, :, 8:33].contiguous(),
-                       "objfeats_32": x[:, :, 33:65].contiguous(),
-                       "room_layout": torch.zeros(B, 1, 64, 64, device=device)}
+        _, self.sample = synth_batch(spec, device, seed=100 + rank)
         self.model = model
         self.opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4},
                                      filter(lambda p: p.requires_grad, model.parameters()))
@@ -124,14 +204,20 @@ def timed(ws, fn):
     return time.perf_counter() - t0
 
 
-def roofline_dominant_kernel(plan, B, N):
+def git_head():
+    try:
+        return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL,
+                                       text=True).strip()
+    except Exception:
+        return None
+
+
+def roofline_dominant_kernel(plan, N, config_name):
     """Time the dominant kernel -- the fused WS-conv + GroupNorm + SiLU GEMM (gemm_kernel<...,GN=true>, K=512) --
     with HIP events on the launch stream, using the very argument structs of the timed plan."""
-    import ctypes as C
+    import torch
     from diffuscene_amd import _lib, ops
     fn = _lib.fn("dsc_gemm_gn_silu_f32")
-    if getattr(plan, "n_chains", 0) > 0:
-        return roofline_scene_chain(plan, B, N)
     steps = [a for f, a in plan.tiled_steps if f is fn]
     structs = [a[0]._obj for a in steps]          # ctypes.byref(struct) keeps the struct in ._obj
     sel = [(a, s) for a, s in zip(steps, structs) if s.k1 + s.k2 == 512]
@@ -147,126 +233,162 @@ def roofline_dominant_kernel(plan, B, N):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / (reps * len(sel))
-    B = plan.B                      # the graph sampler runs the batch as independent half-batch chains
-    flops = 2.0 * B * N * 512 * 512
+    M = plan.B * N
+    flops = 2.0 * M * 512 * 512
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_gemm_gn_hbm_traffic.json")
-    if os.path.exists(tfile) and B * N == 20480:
-        # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), measured
-        # offline on the same workload -- bench.py cannot run the profiler on itself
-        with open(tfile) as f:
-            traffic = round(json.load(f)["hbm_bytes_per_launch"])
-        traffic_src = "profiles/r01_gemm_gn_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-    return {"bound": "mfma", "kernel": "gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512)" % (B * N),
+    # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), measured by
+    # tools/profile_round.sh on the same workload -- bench.py cannot run the profiler on itself; the file records the git
+    # head it was measured at
+    for tfile in ("profiles/r02_gemm_gn_hbm_traffic.json", "profiles/r01_gemm_gn_hbm_traffic.json"):
+        path = os.path.join(ROOT, tfile)
+        if os.path.exists(path) and M == 20480:
+            with open(path) as f:
+                rec = json.load(f)
+            traffic = round(rec["hbm_bytes_per_launch"])
+            traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; measured at git %s)" % (tfile, rec.get("git_head", "?"))
+            break
+    return {"bound": "mfma", "kernel": "gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512)" % M,
             "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
             "launches_per_step": len(steps), "algorithmic_flops_per_launch": flops,
             "traffic": traffic, "traffic_source": traffic_src}
 
 
-def roofline_scene_chain(plan, B, N):
-    """When the plan runs whole ResnetBlocks as scene-resident chains, that kernel carries most of the FLOPs: time every
-    chain launch of the plan with HIP events on the launch stream; algorithmic FLOPs = sum over the chained layers of
-    2*M*n*K.  The tiled GN-GEMM of the one-launch-per-layer plan is timed next to it for comparison."""
-    from diffuscene_amd import _lib, ops
-    chain_f = _lib.fn("dsc_scene_chain_f32")
-    gn_f = _lib.fn("dsc_gemm_gn_silu_f32")
-    chains = [a for f, a in plan.steps if f is chain_f]
-    s = ops.stream_ptr()
-    flops, layers = 0.0, 0
-    for arr, flags, cnt, _n in chains:
-        for j in range(cnt):
-            flops += 2.0 * arr[j].m * arr[j].n * (arr[j].k1 + arr[j].k2)
-            layers += 1
-
-    def timeit(calls, f, reps=3):
-        for a in calls[:2]:
-            f(*a, s)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            for a in calls:
-                f(*a, s)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps          # ms for one pass over `calls`
-    ms_chain = timeit(chains, chain_f)
-    achieved = flops / (ms_chain * 1e-3) / 1e12
-    tiled = [a for f, a in plan.tiled_steps if f is gn_f and a[0]._obj.k1 + a[0]._obj.k2 == 512]
-    ms_tiled = timeit(tiled, gn_f) / max(len(tiled), 1)
-    tiled_tf = 2.0 * plan.B * N * 512 * 512 / (ms_tiled * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "scene_chain_kernel (one workgroup per scene walks %d fused 512-wide layers in %d launches; "
-                                       "WS-conv+GroupNorm+SiLU / res_conv / MLP trunk layers)" % (layers, len(chains)),
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms_chain * 1e3 / len(chains), 2),
-            "launches_per_step": len(chains), "layers_per_step": layers, "algorithmic_flops_per_step": flops,
-            "traffic": None, "traffic_source": None,
-            "tiled_gn_gemm": {"avg_launch_us": round(ms_tiled * 1e3, 2), "achieved": round(tiled_tf, 2),
-                              "frac": round(tiled_tf / PEAK_FP32_MFMA_TFLOPS, 4)}}
+# ------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_info():
+    model, phys = None, None
+    try:
+        cores = set()
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model is None:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        cores.add((pid, cid))
+                    pid = cid = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys
 
 
-def cpu_baseline(args, mode):
-    """The oracle (CPU restatement of the reference path, kind 'port') timed on this box's host cores on a bounded
-    sample: a few steps on a slice of the batch, scaled linearly to the full batch (scenes are independent)."""
+def cpu_baseline(spec, mode):
+    """The oracle (CPU restatement of the reference path, kind 'port', pinned against the real reference by
+    tests/test_oracle.py) timed on this box's host cores: FULL-batch steps of the same workload -- sampling step =
+    Unet1D forward + posterior step; training step = q_sample, forward, p_losses incl. IoU, backward,
+    clip_grad_norm_(10), torch.optim.Adam.step() (diffusion_scene_layout_ddpm.py:456-473)."""
+    import torch
     from oracle import ref_torch as R
     from oracle import weights as W
-    kw = dict(W.UNCOND_LIVING)
+    kw = dict(getattr(W, spec["kw"]))
     sd = W.synth_state_dict(kw)
-    Bs, N = min(args.batch, 64), args.objects
-    x = W.synth_scene_batch(Bs, N, 25, 32, seed=0)
-    cond = W.synth_condition(Bs, N, 128, 0).contiguous()
-    t = torch.full((Bs,), 500, dtype=torch.int64)
+    B, N, nc, kind = spec["batch"], spec["objects"], spec["class_dim"], spec["kind"]
+    x_full = W.synth_scene_batch(B, N, nc, 32, seed=0)
     tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
-    noise = torch.randn(Bs, N, 65)
-
-    def one_sample_step():
-        with torch.no_grad():
-            out = R.unet1d_forward(sd, kw, x, t, cond, None)
-            return R.p_sample_step(tb, x, t, out, noise, True, "v")
-
-    def one_train_step():
-        params = [p.requires_grad_(True) for p in sd.values()]
-        lw, _, _ = R.p_losses(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None), x, t, noise,
-                              R.dims_from_kwargs(kw), True, True, W.DATASET_STATS)
-        lw.mean().backward()
-        for p in params:
-            p.grad = None
-
-    if mode == "both":
-        def fn():
-            one_sample_step()
-            one_train_step()
+    cond = W.synth_condition(B, N, 128, 0).contiguous()
+    cross = W.synth_text_condition(B, spec.get("text_len", 32), 512, 0) if kind == "text" else None
+    if kind == "arrange":
+        cond = torch.cat([cond, torch.randn(B, N, 384)], dim=-1)
+        x = torch.cat([x_full[:, :, 0:3], x_full[:, :, 6:8]], dim=-1).contiguous()
     else:
-        fn = one_sample_step if mode == "sample" else one_train_step
-    # pick the host thread count that runs the oracle fastest on this box (all logical CPUs is rarely it)
+        x = x_full
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(1))
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
+    P = spec.get("partial", 0)
+    pnoise = torch.randn(B, P, x.shape[-1]) if P else None
+    params = [p.requires_grad_(True) for p in sd.values()]
+    opt = torch.optim.Adam(params, lr=2e-4)
+    dims = R.dims_from_kwargs(kw)
+
+    def sample_step(sl=slice(None)):
+        with torch.no_grad():
+            xt = x[sl].clone()
+            if P:       # p_sample_loop_complete: re-noise the given objects, overwrite, then the model call (:461-466)
+                a = tb["sqrt_alphas_cumprod"][t[sl]].view(-1, 1, 1)
+                b = tb["sqrt_one_minus_alphas_cumprod"][t[sl]].view(-1, 1, 1)
+                xt[:, :P] = a * x[sl][:, :P] + b * pnoise[sl]
+            out = R.unet1d_forward(sd, kw, xt, t[sl], cond[sl], None if cross is None else cross[sl])
+            return R.p_sample_step(tb, xt, t[sl], out, noise[sl], True, "v")
+
+    def train_step(sl=slice(None)):
+        opt.zero_grad()
+        if kind == "arrange":
+            lw, _ = R.p_losses_arrange(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond[sl], None), x[sl], t[sl],
+                                       noise[sl])
+        else:
+            lw, _, _ = R.p_losses(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond[sl],
+                                                                      None if cross is None else cross[sl]),
+                                  x[sl], t[sl], noise[sl], dims, True, True, W.DATASET_STATS)
+        lw.mean().backward()
+        torch.nn.utils.clip_grad_norm_(params, 10)
+        opt.step()
+
+    legs = {"sample": [sample_step], "train": [train_step], "both": [sample_step, train_step]}[mode]
+    # pick the host thread count that runs the oracle fastest on this box (all logical CPUs is rarely it), on a quarter batch
     ncpu = os.cpu_count() or 1
+    q = slice(0, max(B // 4, 1))
     best = None
     for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(th)
-        fn()
+        for f in legs:
+            f(q)
         t1 = time.perf_counter()
-        fn()
+        for f in legs:
+            f(q)
         d = time.perf_counter() - t1
-        log("cpu_baseline: %d threads -> %.3f s per %s step on %d scenes" % (th, d, mode, Bs))
+        log("cpu_baseline: %d threads -> %.3f s per %s step on %d scenes" % (th, d, mode, q.stop))
         if best is None or d < best[1]:
             best = (th, d)
         if d > 2.5 * best[1]:
             break                                   # oversubscribed: more threads only get slower
-    cores = best[0]
-    torch.set_num_threads(cores)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        fn()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or n >= 30:
-            break
-    per_full = (el / n) * (args.batch / Bs) / (2.0 if mode == "both" else 1.0)
-    return {"value": round(1.0 / per_full, 4), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "%d %s steps of the oracle on %d of %d scenes (N=%d), scaled x%d to the full batch%s"
-                      % (n, "sample+train pairs" if mode == "both" else mode, Bs, args.batch, N, args.batch // Bs,
-                         "" if mode == "sample" else " (train = fwd+bwd only, no optimizer)")}
+    threads = best[0]
+    torch.set_num_threads(threads)
+    times = {}
+    for f in legs:
+        f()                                         # warm-up at full batch
+        n, t0 = 0, time.perf_counter()
+        while True:
+            f()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > 10.0 or n >= 20:
+                break
+        times[f.__name__] = (el / n, n)
+    per = sum(v[0] for v in times.values()) / len(times)            # 'both': mean of the two step kinds (1:1 mix)
+    model, phys = _cpu_info()
+    out = {"value": round(1.0 / per, 4), "unit": "steps/s", "cores": threads, "kind": "port",
+           "sample": "full-batch oracle steps (B=%d, N=%d): %s; train = q_sample + fwd + p_losses(IoU) + bwd + "
+                     "clip_grad_norm_(10) + Adam.step()" % (B, N, ", ".join("%d x %s %.2f s" % (v[1], k, v[0])
+                                                                           for k, v in times.items())),
+           "threads": threads, "logical_cpus": ncpu, "physical_cores": phys, "cpu_model": model,
+           "torch_version": torch.__version__}
+    for k, v in times.items():
+        out[k.replace("_step", "") + "_steps_per_s"] = round(1.0 / v[0], 4)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: re-exec under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -274,34 +396,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default=os.environ.get("DSC_BENCH_CONFIG", "living80"), choices=sorted(CONFIGS))
     ap.add_argument("--mode", default=os.environ.get("DSC_BENCH_MODE", "both"), choices=["both", "sample", "train"])
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--objects", type=int, default=80)
+    ap.add_argument("--batch", type=int, default=None, help="override the config's per-GPU batch")
+    ap.add_argument("--objects", type=int, default=None, help="override the config's objects per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-loop", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torchrun --nproc-per-node %d, or from a "
+                         "plain shell so that bench.py spawns the ranks itself)" % (args.gpus, ws, args.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if ws > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend="nccl", device_id=device)
     rank = dist.get_rank() if ws > 1 else 0
-    assert ws == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, ws)
 
-    log("building model")
-    model, cfg = build_model(args, device)
+    spec = dict(CONFIGS[args.config])
+    if args.batch:
+        spec["batch"] = args.batch
+    if args.objects:
+        spec["objects"] = args.objects
+    B, N = spec["batch"], spec["objects"]
+    log("building model (%s: B=%d, N=%d)" % (args.config, B, N))
+    model, cfg = build_model(spec, device)
+    if ws > 1:
+        from diffuscene_amd import ddp
+        ddp.broadcast_parameters(model)             # every replica starts from rank 0's weights
     log("model on device")
-    plan = None
     n_s = {"both": (args.steps + 1) // 2, "sample": args.steps, "train": 0}[args.mode]
     n_t = args.steps - n_s
-    sr = SampleRunner(args, model, device) if n_s else None
-    tr = TrainRunner(args, model, device, ws) if n_t else None
+    sr = SampleRunner(spec, model, device, seed=rank) if n_s else None
+    tr = TrainRunner(spec, model, device, rank) if n_t else None
     if sr:
         sr.run(args.warmup)
         sr.reset()
-        plan = sr.g.plan
     if tr:
         tr.run(args.warmup)
 
@@ -318,41 +456,65 @@ def main():
         sr.reset()
         parts["sample"] = timed(ws, lambda: sr.run(n_s)) / n_s
         parts["train"] = timed(ws, lambda: tr.run(n_t)) / max(n_t, 1)
-    tmax = torch.tensor([dt] + [parts.get(k, 0.0) for k in ("sample", "train")], device=device, dtype=torch.float64)
+    full = None
+    if sr and not args.no_full_loop:
+        full = sr.full_loop()
+        log("full 1000-step loop: %.3f s" % full)
+    tmax = torch.tensor([dt] + [parts.get(k, 0.0) for k in ("sample", "train")] + [full or 0.0], device=device,
+                        dtype=torch.float64)
     if ws > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0].item())
     if parts:
         parts = {"sample": float(tmax[1].item()), "train": float(tmax[2].item())}
+    if full is not None:
+        full = float(tmax[3].item())
+    comm = None
+    if ws > 1 and tr:
+        from diffuscene_amd import ddp
+        comm = ddp.measure_allreduce(model, reps=5)         # the gradient exchange alone (no compute to hide behind)
 
     if rank == 0:
-        B, N = args.batch, args.objects
+        kind = spec["kind"]
         steps_per_s = args.steps * ws / dt        # whole job: every rank advances its own B scenes one step
+        what = {"sample": "1000-step sample loop", "train": "train step", "both": "train + 1000-step sample"}[args.mode]
         out = {
-            "metric": "denoiser steps/sec (%s) at B=256, N=80 objects" % (
-                {"sample": "1000-step sample loop", "train": "train step", "both": "train + 1000-step sample"}[args.mode]),
+            "metric": "denoiser steps/sec (%s) at B=%d, N=%d objects" % (what, B, N),
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": ws, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "uncond living/dining rooms (config/uncond/diffusion_livingrooms_instancond_lat32_v.yaml "
-                                   "scaled to N=%d), B=%d scenes per GPU, C=65, T=1000, mode=%s" % (N, B, args.mode),
-                       "global_batch": B * ws, "parallelism": "dp%d" % ws if ws > 1 else "single"},
+            "config": {"workload": "%s (%s), B=%d scenes per GPU, N=%d, C=%d, T=1000, mode=%s"
+                                   % (spec["title"], spec["yaml"], B, N, 8 + spec["class_dim"] + 32, args.mode),
+                       "name": args.config, "global_batch": B * ws,
+                       "parallelism": "dp%d" % ws if ws > 1 else "single"},
+            "git_head": git_head(),
         }
-        F = unet_forward_flops(B, N)
+        F = forward_flops(kind, B, N, spec.get("text_len", 0))
         out["model_tflops"] = round(F * (n_s + 3.0 * n_t) / dt / 1e12, 2)        # per GPU, algorithmic (train = 3F)
         for k, v in parts.items():
             out[k] = {"steps_per_s": round(ws / v, 3), "ms_per_step": round(v * 1e3, 3),
                       "tflops_per_gpu": round((1.0 if k == "sample" else 3.0) * F / v / 1e12, 2)}
         out["model_frac_of_fp32_mfma_peak"] = round(out["model_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        if full is not None:
+            out["full_loop"] = {"steps": 1000, "seconds": round(full, 3), "steps_per_s": round(1000.0 * ws / full, 2),
+                                "what": "wall time of one whole 1000-step p_sample_loop via the captured graph "
+                                        "(x_T draw, 1000 replays, result copy), per-GPU batch %d" % B}
+        if comm is not None:
+            out["allreduce"] = comm
+        plan = sr.g.plan if sr else None
         if plan is None:
             with torch.no_grad():
-                plan = model.diffusion.model.engine(device).prepare(B, N, model._instance_condition(B, device), None)
+                eng = model.diffusion.model.engine(device)
+                ctx_dim = 512 if kind == "arrange" else 128
+                cond = torch.zeros(N, ctx_dim, device=device)[None].expand(B, -1, -1)
+                cross = torch.zeros(B, spec["text_len"], 512, device=device) if kind == "text" else None
+                plan = eng.prepare(B, N, cond, cross)
                 plan.x_in.normal_(); plan.t_in.fill_(500); plan.run()
-        out["roofline"] = roofline_dominant_kernel(plan, B, N)
+        out["roofline"] = roofline_dominant_kernel(plan, N, args.config)
         log("roofline done")
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.mode)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(spec, args.mode)
+        print(json.dumps(out), flush=True)
     if ws > 1:
         dist.barrier()
         dist.destroy_process_group()

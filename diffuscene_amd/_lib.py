@@ -100,7 +100,9 @@ SIGNATURES = {
                                     c_f32p, C.c_void_p]),
     "dsc_scene_chain_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_ddpm_loss_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float),
-                                    c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_void_p]),
+                                    c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
+    "dsc_copy2d_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "dsc_add2d_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_activation_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
     "dsc_transpose_batched_f32": (C.c_int, [C.POINTER(WsItem), C.c_int32, C.c_void_p]),
     "dsc_transpose_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -1288,6 +1288,8 @@ struct LossArgs {
     float* losses; float* parts; float* dout;
     int n, c, tr, sz, bb, nc, no, nf;
     int separate, iou, mean_type;
+    int arrange;                  // re-arrangement model: x = [translation | angle], losses = l_trans + l_angle (:558-571)
+    float grad_scale;             // dout = grad_scale * d losses[b] / d out[b]   (1/B for loss = losses.mean())
     float c_lo[3], c_span[3], s_lo[3], s_span[3];
 };
 
@@ -1329,12 +1331,15 @@ __global__ __launch_bounds__(256) void ddpm_loss_kernel(const LossArgs p) {
     s_cl = block_sum_loss(s_cl, red); s_ob = block_sum_loss(s_ob, red); s_ft = block_sum_loss(s_ft, red);
     s_all = block_sum_loss(s_all, red);
     const float fn = (float)N;
-    const float l_trans = s_tr / (fn * p.tr), l_size = s_sz / (fn * p.sz), l_angle = s_an / (fn * (p.bb - p.tr - p.sz));
-    const float l_bbox = (s_tr + s_sz + s_an) / (fn * p.bb), l_class = s_cl / (fn * p.nc);
-    const float l_obj = s_ob / (fn * (c_obj1 - c_obj0));
+    const float l_trans = s_tr / (fn * p.tr), l_size = p.sz > 0 ? s_sz / (fn * p.sz) : 0.f;
+    const float l_angle = s_an / (fn * (p.bb - p.tr - p.sz));
+    const float l_bbox = (s_tr + s_sz + s_an) / (fn * p.bb), l_class = p.nc > 0 ? s_cl / (fn * p.nc) : 0.f;
+    const float l_obj = (c_obj1 > c_obj0 && !p.arrange) ? s_ob / (fn * (c_obj1 - c_obj0)) : 0.f;
     const float l_feat = p.nf > 0 ? s_ft / (fn * p.nf) : 0.f;
     float losses;
-    if (p.separate) {
+    if (p.arrange && p.separate) {
+        losses = l_trans + l_angle;
+    } else if (p.separate) {
         losses = l_bbox + l_class;
         if (p.no > 0) losses += l_obj;
         if (p.nf > 0) losses += l_feat;
@@ -1450,16 +1455,19 @@ __global__ __launch_bounds__(256) void ddpm_loss_kernel(const LossArgs p) {
     }
     // ---- gradient of losses_weight[b] w.r.t. out[b]
     const float g_bbox = p.separate ? lw * 2.0f / (fn * p.bb) : lw * 2.0f / (fn * C);
-    const float g_class = p.separate ? lw * 2.0f / (fn * p.nc) : g_bbox;
+    const float g_class = p.separate ? (p.nc > 0 ? lw * 2.0f / (fn * p.nc) : 0.f) : g_bbox;
     const float g_obj = p.separate ? (p.no > 0 ? lw * 2.0f / (fn * p.no) : 0.f) : g_bbox;
     const float g_feat = p.separate ? (p.nf > 0 ? lw * 2.0f / (fn * p.nf) : 0.f) : g_bbox;
+    const float g_atr = lw * 2.0f / (fn * p.tr), g_aan = lw * 2.0f / (fn * (p.bb - p.tr - p.sz));   // arrange, separated
     for (int e = tid; e < N * C; e += 256) {
         const int ch = e % C, i = e / C;
         const float d = p.out[base + e] - p.target[base + e];
-        float g = (ch < c_bbox) ? g_bbox : (ch < c_class) ? g_class : (ch < c_obj1) ? g_obj : g_feat;
+        float g;
+        if (p.arrange && p.separate) g = (ch < c_trans) ? g_atr : g_aan;
+        else g = (ch < c_bbox) ? g_bbox : (ch < c_class) ? g_class : (ch < c_obj1) ? g_obj : g_feat;
         g *= d;
         if (p.iou && ch < 6) g += giou[i][ch];
-        p.dout[base + e] = g;
+        p.dout[base + e] = g * p.grad_scale;
     }
 }
 
@@ -1471,11 +1479,15 @@ extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const fl
                                  float* losses, float* parts, float* dout, int32_t b, int32_t n, int32_t c,
                                  int32_t translation_dim, int32_t size_dim, int32_t bbox_dim, int32_t class_dim,
                                  int32_t objectness_dim, int32_t objfeat_dim, int32_t loss_separate, int32_t loss_iou,
-                                 int32_t mean_type, dsc_stream_t stream) {
+                                 int32_t mean_type, float grad_scale, dsc_stream_t stream) {
     if (!target || !out || !x_t || !t || !loss_weight || !losses || !parts || !dout || b < 1 || n < 1) return DSC_EINVAL;
     if (n > LOSS_MAXN) return DSC_ERANGE;
     if (c != bbox_dim + class_dim + objectness_dim + objfeat_dim) return DSC_EINVAL;
-    if (translation_dim != 3 || size_dim != 3) return DSC_ERANGE;
+    // the re-arrangement model diffuses [translation | angle] only (diffusion_ddpm.py:558-571): no size / class /
+    // objectness / shape-code channels, no IoU term
+    const bool arrange = size_dim == 0 && class_dim == 0 && objectness_dim == 0 && objfeat_dim == 0;
+    if (translation_dim != 3 || (size_dim != 3 && !arrange)) return DSC_ERANGE;
+    if (arrange && (loss_iou || bbox_dim <= translation_dim)) return DSC_EINVAL;
     if (loss_iou && (!bounds || !alphas_cumprod)) return DSC_EINVAL;
     if (mean_type != DSC_MEAN_X0 && (!ca || !cb)) return DSC_EINVAL;
     LossArgs p{};
@@ -1483,6 +1495,8 @@ extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const fl
     p.alphas_cumprod = alphas_cumprod; p.losses = losses; p.parts = parts; p.dout = dout;
     p.n = n; p.c = c; p.tr = translation_dim; p.sz = size_dim; p.bb = bbox_dim; p.nc = class_dim; p.no = objectness_dim;
     p.nf = objfeat_dim; p.separate = loss_separate; p.iou = loss_iou; p.mean_type = mean_type;
+    p.arrange = arrange ? 1 : 0;
+    p.grad_scale = grad_scale;
     if (bounds)
         for (int k = 0; k < 3; ++k) {
             p.c_lo[k] = bounds[k]; p.c_span[k] = bounds[3 + k] - bounds[k];
@@ -1492,4 +1506,61 @@ extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const fl
     hipLaunchKernelGGL(ddpm_loss_kernel, dim3(b), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     DSC_LAUNCH_CHECK();
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Strided 2-D helpers of the static training plan (train_plan.py): gradient accumulation of multi-consumer activations
+// (skip connections, residuals) and staging of un-aligned column slices.  16-byte path when everything is aligned.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+template <bool ADD>
+__global__ __launch_bounds__(256) void copy2d_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds,
+                                                     int rows, int cols, int vec) {
+    const long total = vec ? (long)rows * (cols >> 2) : (long)rows * cols;
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (vec) {
+        const int c4n = cols >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const long r = i / c4n;
+            const int c = (int)(i - r * c4n) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + r * lds + c);
+            if (ADD) v += *reinterpret_cast<const f32x4*>(dst + r * ldd + c);
+            *reinterpret_cast<f32x4*>(dst + r * ldd + c) = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const long r = i / cols;
+            const int c = (int)(i - r * cols);
+            float v = src[r * lds + c];
+            if (ADD) v += dst[r * ldd + c];
+            dst[r * ldd + c] = v;
+        }
+    }
+}
+
+template <bool ADD>
+int launch_copy2d(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, int32_t cols, dsc_stream_t stream) {
+    if (!dst || !src || rows < 1 || cols < 1 || ldd < cols || lds < cols) return DSC_EINVAL;
+    const int vec = ((cols | ldd | lds) & 3) == 0 && dsc_aligned16(dst) && dsc_aligned16(src);
+    const long total = vec ? (long)rows * (cols >> 2) : (long)rows * cols;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(copy2d_kernel<ADD>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dst,
+                       (long)ldd, src, (long)lds, rows, cols, vec);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dsc_copy2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, int32_t cols,
+                              dsc_stream_t stream) {
+    return launch_copy2d<false>(dst, ldd, src, lds, rows, cols, stream);
+}
+
+extern "C" int dsc_add2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, int32_t cols,
+                             dsc_stream_t stream) {
+    return launch_copy2d<true>(dst, ldd, src, lds, rows, cols, stream);
 }

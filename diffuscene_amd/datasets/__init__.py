@@ -321,6 +321,13 @@ class SceneBatchLoader:
         sampler = RandomSampler(range(n)) if self.shuffle else SequentialSampler(range(n))
         batches = list(BatchSampler(sampler, self.batch_size, self.drop_last))
         if self.world_size > 1:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world_size:
+                # every rank drew an epoch order from ITS generator (keeps each rank's RNG stream where a single-GPU run
+                # would leave it); the shards must come from ONE order, so rank 0's is broadcast
+                box = [batches]
+                dist.broadcast_object_list(box, src=0)
+                batches = box[0]
             usable = len(batches) // self.world_size * self.world_size
             batches = batches[self.rank:usable:self.world_size]
         return batches

@@ -3,12 +3,17 @@ calls torch.distributed).
 
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
 Scenes are independent, so the batch is sharded over ranks with no data-path collective; the ONLY exchange is
-one averaged all-reduce of the 77.7 M fp32 gradients per step.  Gradients are packed into a few large
-contiguous buckets (default 128 MiB: xGMI is point-to-point, per-link bandwidth-bound, so few large
-messages beat many small ones).  ``OverlappedGradientReducer`` launches a bucket's asynchronous all-reduce from
-gradient hooks as soon as backward has produced its last gradient, so the exchange overlaps the rest of backward;
-``average_gradients`` is the non-overlapped form (all buckets after backward).  The global-norm clip then runs on the
-reduced gradients, identical on every rank, with no extra collective.
+one summed all-reduce of the 77.7 M fp32 gradients per step (the 1/world factor is folded into the loss gradient).
+
+``FlatGradientReducer`` (default, with the static training plan): gradients live in ONE flat buffer G (flat.py); G is cut
+into >= 8 contiguous buckets (~39 MB: xGMI is point-to-point and per-link bandwidth-bound, so few large messages beat many
+small ones, but a bucket must be finished by the backward before it can leave) and each bucket is all-reduced IN PLACE -- no
+pack, no copy-back -- as soon as the launch that finishes it has been enqueued, while the rest of the backward keeps
+running on the compute stream.  The plan fixes the bucket -> launch schedule at build time, identically on every rank.
+
+``OverlappedGradientReducer`` / ``average_gradients`` serve the autograd fallback path (per-parameter gradients): buckets are
+packed from gradient hooks during backward.  The global-norm clip always runs on the reduced gradients, identical on every
+rank, with no extra collective.  ``broadcast_parameters`` makes every replica start from rank 0's weights.
 """
 import os
 
@@ -185,3 +190,101 @@ def init_from_env(backend=None):
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend)
     return world()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flat-buffer path (static training plan)
+# ---------------------------------------------------------------------------------------------------------------------
+N_BUCKETS = int(os.environ.get("DSC_DDP_BUCKETS", "8"))
+
+
+class FlatGradientReducer:
+    """In-place bucketed all-reduce of the flat gradient buffer, driven by the training plan's launch schedule."""
+
+    def __init__(self, flat, plan, n_buckets=None):
+        self.flat = flat
+        self.buckets = flat.buckets(n_buckets or N_BUCKETS)
+        sched = plan.bucket_schedule(self.buckets)
+        self.at_launch = {}
+        self.at_finish = list(sched.get(None, []))
+        for idx, bs in sched.items():
+            if idx is None:
+                continue
+            for b in bs:
+                # buckets that reach into the wrapper-level region also receive gradients from autograd AFTER the plan ran
+                if self.buckets[b][0] < flat.head_floats:
+                    self.at_finish.append(b)
+                else:
+                    self.at_launch.setdefault(idx, []).append(b)
+        self.pending = []
+        self.launched_during_backward = 0
+        self.order = []                       # bucket ids in launch order of the last step (tests)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        self.pending.append(dist.all_reduce(self.flat.G[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self.order.append(b)
+
+    def on_progress(self, i):
+        bs = self.at_launch.get(i)
+        if bs:
+            for b in bs:
+                self._launch(b)
+                self.launched_during_backward += 1
+
+    def finish(self):
+        """-> number of bucket all-reduces of this step; returns when the current stream may read the reduced G."""
+        for b in sorted(set(self.at_finish)):
+            self._launch(b)
+        n = len(self.pending)
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        self.last_order, self.order = self.order, []
+        return n
+
+
+def broadcast_parameters(module, src=0):
+    """Every replica starts from rank ``src``'s parameters and buffers (one broadcast of the flat buffer when the module has
+    been flattened)."""
+    if world() == 1:
+        return
+    fs = getattr(module, "_dsc_flat", None)
+    with torch.no_grad():
+        if fs is not None and fs.valid():
+            dist.broadcast(fs.P, src=src)
+            done = {id(p) for p in fs.params}
+        else:
+            done = set()
+        for p in module.parameters():
+            if id(p) not in done:
+                dist.broadcast(p.data, src=src)
+        for b in module.buffers():
+            dist.broadcast(b, src=src)
+
+
+def measure_allreduce(module, reps=5):
+    """The gradient exchange alone (no compute to hide behind): all buckets of G all-reduced back to back, per step."""
+    fs = getattr(module, "_dsc_flat", None)
+    if fs is None or world() == 1:
+        return None
+    buckets = fs.buckets(N_BUCKETS)
+    g = torch.zeros_like(fs.G)
+
+    def once():
+        works = [dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e in buckets]
+        for w in works:
+            w.wait()
+    once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = fs.numel * 4
+    return {"backend": dist.get_backend(), "world": world(), "buckets": len(buckets), "bytes": nbytes,
+            "ms_per_step": round(ms, 3), "algbw_GBps": round(nbytes / ms / 1e6, 1),
+            "busbw_GBps": round(nbytes / ms / 1e6 * 2 * (world() - 1) / world(), 1)}

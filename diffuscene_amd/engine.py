@@ -404,10 +404,10 @@ class DenoiserEngine:
         self.time_freq = net.time_freq.to(device)
 
     def _signature(self):
-        v = 0
-        for p in self.net.parameters():
-            v += p._version + (p.data_ptr() & 0xFFFFFFF)
-        return v
+        """Order-sensitive fingerprint of (version, pointer) of every parameter + the epoch counter of raw-pointer
+        optimizer updates (optim.FusedAdam also bumps p._version; the counter covers updates that could not)."""
+        from .optim import weights_epoch
+        return hash((weights_epoch(),) + tuple((p._version, p.data_ptr()) for p in self.net.parameters()))
 
     def refresh(self, force=False):
         """Re-derive standardised / packed weights if any parameter changed (in-place update or reallocation)."""

@@ -280,10 +280,23 @@ class GaussianDiffusion:
         model_output = denoise_fn(data, t, condition, condition_cross)
         tb = self.tables(data.device)
         ca, cb = self._coeffs(tb)
-        x_recon = torch.empty_like(data)
-        model_mean = ops.p_sample(data.contiguous(), model_output.contiguous(), torch.zeros_like(data), t, ca, cb,
-                                  tb["posterior_mean_coef1"], tb["posterior_mean_coef2"], self._sigma(tb),
-                                  _MEAN[self.model_mean_type], clip_denoised, x0_out=x_recon)
+        if torch.is_grad_enabled() and model_output.requires_grad:
+            # loss_type 'kl' training (:657-660): the KL back-propagates through model_mean to the denoiser, so this
+            # branch stays on differentiable device ops over the same tables (the fused kernel has no autograd)
+            if self.model_mean_type == 'eps':
+                x_recon = self._predict_xstart_from_eps(data, t, eps=model_output)
+            elif self.model_mean_type == 'x0':
+                x_recon = model_output
+            else:
+                x_recon = self._predict_start_from_v(data, t, v=model_output)
+            if clip_denoised:
+                x_recon = torch.clamp(x_recon, -1.0, 1.0)
+            model_mean, _, _ = self.q_posterior_mean_variance(x_start=x_recon, x_t=data, t=t)
+        else:
+            x_recon = torch.empty_like(data)
+            model_mean = ops.p_sample(data.contiguous(), model_output.contiguous(), torch.zeros_like(data), t, ca, cb,
+                                      tb["posterior_mean_coef1"], tb["posterior_mean_coef2"], self._sigma(tb),
+                                      _MEAN[self.model_mean_type], clip_denoised, x0_out=x_recon)
         var_tab = tb["posterior_variance"] if self.model_var_type == 'fixedsmall' else tb["betas"]
         logvar_tab = (tb["posterior_log_variance_clipped"] if self.model_var_type == 'fixedsmall'
                       else tb["_logvar_large"])

@@ -50,11 +50,16 @@ class DiffusionSceneLayout_DDPM(Module):
                     p.requires_grad = False
                 print('use text as condition, and pretrained clip embedding')
             else:
-                from transformers import BertModel, BertTokenizer
-                self.tokenizer = BertTokenizer.from_pretrained('bert-base-cased')
-                self.bertmodel = BertModel.from_pretrained("bert-base-cased")
-                for p in self.bertmodel.parameters():
-                    p.requires_grad = False
+                # ``text_bert_cached: true`` (new key, default false = reference behaviour): the frozen BERT encoder is not
+                # instantiated; batches carry its cached last_hidden_state as ``desc_bert`` (B, L, 768), produced once
+                # per description by diffuscene_amd.text_cache.BertFeatureCache
+                self.text_bert_cached = config.get("text_bert_cached", False)
+                if not self.text_bert_cached:
+                    from transformers import BertModel, BertTokenizer
+                    self.tokenizer = BertTokenizer.from_pretrained('bert-base-cased')
+                    self.bertmodel = BertModel.from_pretrained("bert-base-cased")
+                    for p in self.bertmodel.parameters():
+                        p.requires_grad = False
                 self.fc_text_f = nn.Linear(768, text_embed_dim)
                 print('use text as condition, and pretrained bert model')
         else:
@@ -126,7 +131,11 @@ class DiffusionSceneLayout_DDPM(Module):
             return room_layout_f[:, None, :].repeat(1, num_points, 1)
         return inst
 
-    def _text_condition(self, text, desc_emb, device):
+    def attach_bert_cache(self, cache):
+        """Use a text_cache.BertFeatureCache for the descriptions instead of running BERT inside every step."""
+        object.__setattr__(self, "_bert_cache", cache)
+
+    def _text_condition(self, text, desc_emb, device, desc_bert=None):
         if not self.text_condition:
             return None
         if self.text_glove_embedding:
@@ -134,6 +143,14 @@ class DiffusionSceneLayout_DDPM(Module):
         if self.text_clip_embedding:
             import clip
             return self.clip_model.encode_text(clip.tokenize(text).to(device))
+        cache = getattr(self, "_bert_cache", None)
+        if desc_bert is None and cache is not None:
+            desc_bert = cache.batch(text, device)                # frozen encoder: features are a function of the text only
+        if desc_bert is not None:
+            return self.fc_text_f(desc_bert)
+        if getattr(self, "text_bert_cached", False):
+            raise KeyError("text_bert_cached: the batch must carry 'desc_bert' (B, L, 768) or a BertFeatureCache must be "
+                           "attached (attach_bert_cache)")
         tokenized = self.tokenizer(text, return_tensors='pt', padding=True).to(device)
         return self.fc_text_f(self.bertmodel(**tokenized).last_hidden_state)
 
@@ -144,6 +161,12 @@ class DiffusionSceneLayout_DDPM(Module):
     # ------------------------------------------------------------------------------------ training
     def get_loss(self, sample_params):
         """reference :131-226"""
+        target, condition, condition_cross = self._loss_inputs(sample_params)
+        return self.diffusion.get_loss_iter(target, condition=condition, condition_cross=condition_cross)
+
+    def _loss_inputs(self, sample_params):
+        """The part of get_loss before the diffusion call (:131-221): diffusion target (B, N, C), per-object condition and
+        cross-attention condition."""
         class_labels = sample_params["class_labels"]
         translations, sizes, angles = sample_params["translations"], sample_params["sizes"], sample_params["angles"]
         batch_size, num_points, _ = class_labels.shape
@@ -175,8 +198,9 @@ class DiffusionSceneLayout_DDPM(Module):
                                   dim=-1).contiguous()
             tr, sz, bb = self.translation_dim, self.size_dim, self.bbox_dim
             target = torch.cat([target[:, :, 0:tr], target[:, :, tr + sz:bb]], dim=-1).contiguous()
-        condition_cross = self._text_condition(sample_params.get("description"), sample_params.get("desc_emb"), device)
-        return self.diffusion.get_loss_iter(target, condition=condition, condition_cross=condition_cross)
+        condition_cross = self._text_condition(sample_params.get("description"), sample_params.get("desc_emb"), device,
+                                               desc_bert=sample_params.get("desc_bert"))
+        return target, condition, condition_cross
 
     # ------------------------------------------------------------------------------------ sampling
     def sample(self, room_mask, num_points, point_dim, batch_size=1, text=None, partial_boxes=None,
@@ -279,18 +303,30 @@ class DiffusionSceneLayout_DDPM(Module):
 
 
 def train_on_batch(model, optimizer, sample_params, config):
-    """reference :456-473: zero_grad, loss, backward, clip_grad_norm_(max_grad_norm), optimizer step.  All logged
-    scalars are fetched with one device->host copy; under torch.distributed the gradients are averaged over the
-    ranks (RCCL all-reduce over xGMI) before clipping, so every rank clips and steps identically."""
+    """reference :456-473: zero_grad, loss, backward, clip_grad_norm_(max_grad_norm), optimizer step.
+
+    Default path: the static training plan (train_step.py / train_plan.py) -- forward, loss and backward are one hipGraph
+    replay that leaves every gradient in the flat buffer G; under torch.distributed the buckets of G are all-reduced over
+    RCCL while the backward is still running, so every rank clips and steps identically.  Configurations the plan does not
+    cover run the same HIP kernels under torch.autograd (autograd_ops.py).  All logged scalars are fetched with one
+    device->host copy."""
     from ..ddp import average_gradients, clip_grad_norm_fused, overlapped_reducer
-    optimizer.zero_grad()
-    reducer = overlapped_reducer(model)      # None on one GPU; hooks launch bucket all-reduces during backward
-    loss, loss_dict = model.get_loss(sample_params)
-    loss.backward()
-    if reducer is not None:
-        reducer.finish()
+    from ..train_step import loss_step, plan_supported
+    if plan_supported(model):
+        # optimizer.zero_grad(): every gradient is OVERWRITTEN by the plan, so nothing is zeroed or freed; only a pending
+        # deferred clip coefficient is cancelled (FusedAdam)
+        if hasattr(optimizer, "cancel_pending_clip"):
+            optimizer.cancel_pending_clip()
+        loss, loss_dict, _ = loss_step(model, sample_params, backward=True)
     else:
-        average_gradients(model)             # no-op on one GPU; DSC_DDP_OVERLAP=0 selects this post-backward form
+        optimizer.zero_grad()
+        reducer = overlapped_reducer(model)      # None on one GPU; hooks launch bucket all-reduces during backward
+        loss, loss_dict = model.get_loss(sample_params)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        else:
+            average_gradients(model)             # no-op on one GPU; DSC_DDP_OVERLAP=0 selects this post-backward form
     if hasattr(optimizer, "clip_grad_norm_"):         # FusedAdam: norm + coefficient on the device, applied in step()
         grad_norm = optimizer.clip_grad_norm_(config["training"]["max_grad_norm"])
     else:
@@ -308,7 +344,11 @@ def train_on_batch(model, optimizer, sample_params, config):
 
 @torch.no_grad()
 def validate_on_batch(model, sample_params, config):
-    loss, loss_dict = model.get_loss(sample_params)
+    from ..train_step import loss_step, plan_supported
+    if plan_supported(model):
+        loss, loss_dict, _ = loss_step(model, sample_params, backward=False)
+    else:
+        loss, loss_dict = model.get_loss(sample_params)
     keys = list(loss_dict.keys())
     packed = torch.stack([loss.detach()] + [loss_dict[k].detach() for k in keys]).tolist()
     for k, v in zip(keys, packed[1:]):

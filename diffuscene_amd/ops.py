@@ -398,8 +398,9 @@ def activation_bwd(x, dy, act):
     return dx
 
 
-def ddpm_loss(target, out, x_t, t, loss_weight, ca, cb, alphas_cumprod, bounds, dims, separate, iou, mean_type):
-    """-> losses_weight [B], parts [B, 9], dout [B, N, C] (d losses_weight[b] / d out[b])"""
+def ddpm_loss(target, out, x_t, t, loss_weight, ca, cb, alphas_cumprod, bounds, dims, separate, iou, mean_type,
+              grad_scale=1.0):
+    """-> losses_weight [B], parts [B, 9], dout [B, N, C] (grad_scale * d losses_weight[b] / d out[b])"""
     _c(target, "target"); _c(out, "out"); _c(x_t, "x_t"); _dev(t, "t", torch.int64)
     B, N, Cc = out.shape
     losses = torch.empty((B,), device=out.device, dtype=torch.float32)
@@ -412,5 +413,5 @@ def ddpm_loss(target, out, x_t, t, loss_weight, ca, cb, alphas_cumprod, bounds, 
         alphas_cumprod.data_ptr() if alphas_cumprod is not None else None, barr,
         losses.data_ptr(), parts.data_ptr(), dout.data_ptr(), B, N, Cc, dims["translation_dim"], dims["size_dim"],
         dims["bbox_dim"], dims["class_dim"], dims["objectness_dim"], dims["objfeat_dim"], 1 if separate else 0,
-        1 if iou else 0, mean_type, stream_ptr()), "dsc_ddpm_loss_f32")
+        1 if iou else 0, mean_type, float(grad_scale), stream_ptr()), "dsc_ddpm_loss_f32")
     return losses, parts, dout

@@ -13,6 +13,17 @@ from . import _lib
 
 CHUNK = 32768
 
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_epoch():
+    """Counter bumped by every raw-pointer parameter update of this module (part of DenoiserEngine's signature)."""
+    return _WEIGHTS_EPOCH[0]
+
+
+def _bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
 
 class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
@@ -86,22 +97,35 @@ class FusedAdam(torch.optim.Adam):
                     "dev": torch.empty((len(tix), 5), dtype=torch.int64, device=dev),
                     "partial": torch.empty((len(tix),), dtype=torch.float64, device=dev),
                     "norm": torch.zeros((), dtype=torch.float32, device=dev),
-                    "coef": torch.ones((), dtype=torch.float32, device=dev)}
+                    "coef": torch.ones((), dtype=torch.float32, device=dev), "gptr": None, "uploaded": None}
             self._plans[gi] = plan
         for p in ps:
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
         gptr = np.array([p.grad.data_ptr() for p in ps], dtype=np.int64)
-        plan["table"][:, 1] = gptr[plan["tix"]] + plan["off4"]
-        plan["host"].copy_(torch.from_numpy(plan["table"]))
-        plan["dev"].copy_(plan["host"], non_blocking=True)
+        if plan.get("gptr") is None or not np.array_equal(gptr, plan["gptr"]):
+            # the pinned staging buffer may still be the source of the previous step's asynchronous upload: wait for that
+            # copy before rewriting it (callers other than train_on_batch do not synchronise between steps)
+            if plan.get("uploaded") is not None:
+                plan["uploaded"].synchronize()
+            plan["table"][:, 1] = gptr[plan["tix"]] + plan["off4"]
+            plan["host"].copy_(torch.from_numpy(plan["table"]))
+            plan["dev"].copy_(plan["host"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(plan["dev"].device))
+            plan["uploaded"] = ev
+            plan["gptr"] = gptr
         return plan
 
     # ---- clip + step ---------------------------------------------------------------------------------------------
     @torch.no_grad()
     def clip_grad_norm_(self, max_norm):
-        """Global L2 norm of all gradients of all groups and the clip coefficient, both left on the device; the
-        coefficient is applied inside the next ``step()``.  Returns the total norm (0-d device tensor)."""
+        """Global L2 norm of all gradients and the clip coefficient, both left on the device.  DEFERRED clip: unlike
+        ``torch.nn.utils.clip_grad_norm_`` the gradients are NOT scaled in place -- the coefficient is applied inside the
+        next ``step()`` while the Adam sweep reads them (readers of ``p.grad`` between the two calls see the unclipped
+        values; the returned norm is the pre-clip norm, as in torch).  ``zero_grad()`` cancels a pending coefficient.
+        With several param groups the gradients are clipped in place (torch semantics) and ``step()`` runs unclipped.
+        Returns the total norm (0-d device tensor)."""
         plans = []
         for gi, group in enumerate(self.param_groups):
             ps = self._active(group)
@@ -110,7 +134,10 @@ class FusedAdam(torch.optim.Adam):
         if not plans:
             return torch.zeros(())
         if len(plans) != 1:
-            raise NotImplementedError("FusedAdam.clip_grad_norm_ with several param groups")
+            from .ddp import clip_grad_norm_fused
+            for pl in plans:
+                pl["clip_ready"] = False
+            return clip_grad_norm_fused([p for g in self.param_groups for p in g["params"]], max_norm)
         plan = plans[0]
         dev = plan["dev"].device
         with torch.cuda.device(dev):
@@ -122,6 +149,14 @@ class FusedAdam(torch.optim.Adam):
                                                     plan["coef"].data_ptr(), s), "dsc_clip_coef_f32")
         plan["clip_ready"] = True
         return plan["norm"]
+
+    def cancel_pending_clip(self):
+        for plan in self._plans.values():
+            plan["clip_ready"] = False          # a coefficient computed for gradients that no longer exist must not be applied
+
+    def zero_grad(self, set_to_none=True):
+        self.cancel_pending_clip()
+        return super().zero_grad(set_to_none=set_to_none)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -160,4 +195,8 @@ class FusedAdam(torch.optim.Adam):
                                "dsc_adam_step_f32")
             for p in ps:
                 self._steps[id(p)] += 1
+            # the kernel wrote the parameters through raw pointers: tell autograd / the engine's derived-weight cache
+            # (DenoiserEngine._signature reads p._version) that they changed
+            torch.autograd.graph.increment_version(ps)
+            _bump_weights_epoch()
         return loss

@@ -1,0 +1,912 @@
+"""Static training plan: the whole DDPM training step of the denoiser -- q_sample, Unet1D forward (reference
+denoise_net.py:507-593), the p_losses objective (diffusion_ddpm.py:520-652) and the hand-written backward of every layer --
+flattened ONCE into two launch lists over statically allocated buffers.
+
+What this replaces: round 1 ran the backward through ``torch.autograd`` (autograd_ops.py: one Function per fused op).  That
+path allocates every activation and gradient per step, accumulates multi-consumer gradients with ATen adds, concatenates
+the packed conditioning weights with ``torch.cat`` and leaves ~135 fills / 65 adds / 24 cats per step between the HIP
+kernels.  Here
+
+* every buffer is allocated when the plan is built; a step is a loop of C-ABI calls with fixed pointers, so the whole step
+  (forward + loss + backward + gradient norm) is captured in ONE hipGraph on a single GPU;
+* weight gradients are written by the TN GEMMs directly into the flat gradient buffer ``G`` (flat.py); the packed time /
+  context MLP weights and their gradients are views of ``P`` / ``G``;
+* gradients of multi-consumer activations (skip connections, residuals) are accumulated by the GEMM epilogue
+  (``residual == y``) or aliased, not by separate add kernels, wherever the dataflow allows;
+* under data parallelism the plan knows which launch finishes which slice of ``G`` and hands finished buckets to the reducer
+  while the rest of the backward is still being enqueued.
+
+The plan is written against a tiny op vocabulary (``gemm``, ``gemm_gn``, ``gemm_tn``, ``gn_bwd`` ...) that a backend lowers.
+``HipBackend`` lowers to libdiffuscene_hip.so calls (the product).  tests/plan_sim.py provides a CPU backend of the same
+vocabulary on torch ops so that the plan's dataflow (buffer aliasing, accumulation order, slices) is verified against
+torch.autograd without a GPU; the product never imports it.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, SS_NONE, SS_PER_SCENE, SS_PER_SLOT, SS_PER_TOKEN
+
+D = 512
+HID = 128
+
+
+def _as2d(w):
+    return w.view(w.shape[0], w.shape[1]) if w.dim() == 3 else w
+
+
+class H:
+    """Activation handle: forward tensor + (build-time) gradient tensor."""
+    __slots__ = ("t", "g", "ng")
+
+    def __init__(self, t, needs_grad=True):
+        self.t, self.g, self.ng = t, None, needs_grad
+
+
+# ======================================================================================================================
+class HipBackend:
+    """Lowers plan ops to (cfunc, args) launches of libdiffuscene_hip.so with pointers fixed at build time."""
+
+    name = "hip"
+
+    def __init__(self, device):
+        from . import _lib
+        _lib.load()
+        self.lib = _lib
+        self.device = device
+        self.keep = []
+        self.scratch_floats = 0
+        self.scratch = None
+        self._scratch_users = []
+
+    # -- helpers
+    def _mat(self, t):
+        from .ops import _mat
+        return _mat(t, "plan tensor")
+
+    def _call(self, name, *args, keep=()):
+        self.keep.append(keep)
+        return (self.lib.fn(name), args, name)
+
+    def finalize(self):
+        """Allocate the shared split-reduction workspace (kernels of one stream run in order, so it is shared)."""
+        self.scratch = torch.empty(max(self.scratch_floats, 1), device=self.device, dtype=torch.float32)
+        for fix in self._scratch_users:
+            fix(self.scratch)
+
+    def _with_scratch(self, floats, build):
+        """``build(ptr, floats)`` -> step; the pointer is patched in once the workspace exists."""
+        self.scratch_floats = max(self.scratch_floats, int(floats))
+        holder = {}
+
+        def fix(scr):
+            holder["step"] = build(scr.data_ptr(), scr.numel())
+        self._scratch_users.append(fix)
+        return holder
+
+    # -- forward ops
+    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE):
+        from . import ops
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
+        return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual))
+
+    def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):
+        from . import ops
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5, tokens_per_scene=n_tok,
+                               scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE, preact=preact)
+        return self._call("dsc_gemm_gn_silu_f32", C.byref(g), keep=(g, a, w, out, bias, gamma, beta, a2, ss, residual, preact))
+
+    def smallk(self, x, w, bias, out, act_out=ACT_NONE):
+        xp, ldx = self._mat(x)
+        wp, ldw = self._mat(w)
+        yp, ldy = self._mat(out)
+        return self._call("dsc_linear_smallk_f32", xp, ldx, x.shape[1], wp, ldw, bias.data_ptr() if bias is not None else None,
+                          yp, ldy, x.shape[0], w.shape[0], act_out, keep=(x, w, bias, out))
+
+    def ws(self, weights, outs):
+        from . import ops
+        steps = []
+        for i in range(0, len(weights), self.lib.WS_MAX):
+            arr = ops.make_ws_items(list(zip(weights[i:i + self.lib.WS_MAX], outs[i:i + self.lib.WS_MAX])))
+            steps.append(self._call("dsc_weight_standardize_f32", arr, len(arr), 1e-5, keep=(arr, weights, outs)))
+        return steps
+
+    def time_embedding(self, t, table, freq, out):
+        return self._call("dsc_time_embedding_f32", t.data_ptr(), t.shape[0], out.shape[1], table.data_ptr(), table.shape[0],
+                          freq.data_ptr(), out.data_ptr(), keep=(t, table, freq, out))
+
+    def act(self, x, out, kind):
+        assert x.is_contiguous() and out.is_contiguous()
+        return self._call("dsc_activation_f32", x.data_ptr(), out.data_ptr(), x.numel(), kind, keep=(x, out))
+
+    def layernorm(self, x, g, out, residual=None):
+        xp, ldx = self._mat(x)
+        yp, ldy = self._mat(out)
+        rp, ldr = self._mat(residual) if residual is not None else (None, 0)
+        return self._call("dsc_layernorm_f32", xp, ldx, g.data_ptr(), rp, ldr, yp, ldy, x.shape[0], x.shape[1], 1e-5,
+                          keep=(x, g, out, residual))
+
+    def linattn(self, q, k, v, out, scenes, nq, nk, scale):
+        a = []
+        for t in (q, k, v, out):
+            a += list(self._mat(t))
+        return self._call("dsc_linear_attention_f32", *a, scenes, nq, nk, scale, keep=(q, k, v, out))
+
+    def attn(self, q, k, v, out, scenes, n, scale):
+        a = []
+        for t in (q, k, v, out):
+            a += list(self._mat(t))
+        return self._call("dsc_attention_f32", *a, scenes, n, scale, keep=(q, k, v, out))
+
+    def q_sample(self, x0, noise, t, sqrt_ac, sqrt_1mac, xt, v):
+        b = x0.shape[0]
+        return self._call("dsc_q_sample_f32", x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(),
+                          sqrt_1mac.data_ptr(), xt.data_ptr(), v.data_ptr() if v is not None else None, b, x0.numel() // b,
+                          keep=(x0, noise, t, sqrt_ac, sqrt_1mac, xt, v))
+
+    def loss(self, target, out, x_t, t, tb, ca, cb, bounds, dims, separate, iou, mean_type, losses, parts, dout, scale):
+        B, N, Cc = out.shape
+        barr = (C.c_float * 12)(*[float(v) for v in bounds]) if bounds is not None else None
+        return self._call("dsc_ddpm_loss_f32", target.data_ptr(), out.data_ptr(), x_t.data_ptr(), t.data_ptr(),
+                          tb["loss_weight"].data_ptr(), ca.data_ptr() if ca is not None else None,
+                          cb.data_ptr() if cb is not None else None, tb["alphas_cumprod"].data_ptr(), barr,
+                          losses.data_ptr(), parts.data_ptr(), dout.data_ptr(), B, N, Cc, dims["translation_dim"],
+                          dims["size_dim"], dims["bbox_dim"], dims["class_dim"], dims["objectness_dim"], dims["objfeat_dim"],
+                          1 if separate else 0, 1 if iou else 0, mean_type, float(scale),
+                          keep=(target, out, x_t, t, tb, ca, cb, barr, losses, parts, dout))
+
+    # -- backward ops
+    def gemm_tn(self, a, dy, out, a2=None, kvalid=None, dbias=None):
+        ap, lda = self._mat(a)
+        dp, ldd = self._mat(dy)
+        a2p, lda2, k2 = (None, 0, 0)
+        if a2 is not None:
+            a2p, lda2 = self._mat(a2)
+            k2 = a2.shape[1]
+        k1 = a.shape[1]
+        kv = (k1 + k2) if kvalid is None else kvalid
+        m, n = dy.shape
+        op, ldo = self._mat(out)
+        wsf = self.lib.fn("dsc_gemm_tn_workspace_floats")(m, n, kv)
+        fn = self.lib.fn("dsc_gemm_tn_f32")
+        self.keep.append((a, dy, out, a2, dbias))
+        dbp = dbias.data_ptr() if dbias is not None else None
+        return self._with_scratch(wsf, lambda wp, wn: (fn, (ap, lda, k1, a2p, lda2, k2, dp, ldd, op, ldo, dbp, m, n, kv,
+                                                            wp if wsf else None, wn if wsf else 0), "dsc_gemm_tn_f32"))
+
+    def colsum(self, x, out):
+        xp, ldx = self._mat(x)
+        m, n = x.shape
+        fn = self.lib.fn("dsc_colsum_f32")
+        self.keep.append((x, out))
+        op = out.data_ptr()
+        return self._with_scratch(64 * n, lambda wp, wn: (fn, (xp, ldx, m, n, op, wp, wn), "dsc_colsum_f32"))
+
+    def gn_bwd(self, z, dy, gamma, beta, ss, ss_mode, dz, part, dss, scenes, n_tok):
+        zp, ldz = self._mat(z)
+        dp, ldy = self._mat(dy)
+        dzp, lddz = self._mat(dz)
+        Cc = z.shape[1]
+        sp, ld_ss = self._mat(ss) if ss is not None else (None, 0)
+        dsp, ld_dss = self._mat(dss) if dss is not None else (None, 0)
+        pp = part.data_ptr()                       # row layout [dbias | dgamma | dbeta] (the order of the parameters in G)
+        return self._call("dsc_gn_silu_bwd_f32", zp, ldz, dp, ldy, gamma.data_ptr(), beta.data_ptr(), sp, ld_ss,
+                          ss_mode if sp else SS_NONE, dzp, lddz, pp + 4 * Cc, pp + 8 * Cc, pp, part.stride(0), dsp, ld_dss,
+                          scenes, n_tok, Cc, 1e-5, keep=(z, dy, gamma, beta, ss, dz, part, dss))
+
+    def ws_bwd(self, weights, dws, outs):
+        steps = []
+        for i in range(0, len(weights), self.lib.WS_MAX):
+            ws_, gs, os_ = weights[i:i + self.lib.WS_MAX], dws[i:i + self.lib.WS_MAX], outs[i:i + self.lib.WS_MAX]
+            arr = (self.lib.WsBwdItem * len(ws_))()
+            for j, (w, g, o) in enumerate(zip(ws_, gs, os_)):
+                w2, o2 = _as2d(w), _as2d(o)
+                assert w2.is_contiguous() and g.is_contiguous() and o2.is_contiguous()
+                arr[j].w, arr[j].dw_std, arr[j].dw = w2.data_ptr(), g.data_ptr(), o2.data_ptr()
+                arr[j].rows, arr[j].cols = w2.shape
+            steps.append(self._call("dsc_weight_standardize_bwd_f32", arr, len(ws_), 1e-5, keep=(arr, ws_, gs, os_)))
+        return steps
+
+    def layernorm_bwd(self, x, g, dy, dx, dg_part):
+        xp, ldx = self._mat(x)
+        dp, ldy = self._mat(dy)
+        dxp, lddx = self._mat(dx)
+        return self._call("dsc_layernorm_bwd_f32", xp, ldx, g.data_ptr(), dp, ldy, dxp, lddx, dg_part.data_ptr(),
+                          dg_part.shape[0], x.shape[0], x.shape[1], 1e-5, keep=(x, g, dy, dx, dg_part))
+
+    def linattn_bwd(self, q, k, v, dout, dq, dk, dv, scenes, nq, nk, scale):
+        a = []
+        for t in (q, k, v, dout, dq, dk, dv):
+            a += list(self._mat(t))
+        return self._call("dsc_linear_attention_bwd_f32", *a, scenes, nq, nk, scale, keep=(q, k, v, dout, dq, dk, dv))
+
+    def attn_bwd(self, q, k, v, dout, dq, dk, dv, scenes, n, scale):
+        a = []
+        for t in (q, k, v, dout, dq, dk, dv):
+            a += list(self._mat(t))
+        return self._call("dsc_attention_bwd_f32", *a, scenes, n, scale, keep=(q, k, v, dout, dq, dk, dv))
+
+    def act_bwd(self, x, dy, dx, kind):
+        assert x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous()
+        return self._call("dsc_activation_bwd_f32", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), kind,
+                          keep=(x, dy, dx))
+
+    def transpose_many(self, pairs):
+        """pairs of (w [r,c] contiguous, out [c,r] contiguous) -> batched launches; strided outputs -> single launches."""
+        steps, batch = [], []
+        for w, o in pairs:
+            if w.is_contiguous() and o.is_contiguous():
+                batch.append((w, o))
+            else:
+                wp, ldi = self._mat(w)
+                op, ldo = self._mat(o)
+                steps.append(self._call("dsc_transpose_f32", wp, ldi, op, ldo, w.shape[0], w.shape[1], keep=(w, o)))
+        for i in range(0, len(batch), self.lib.WS_MAX):
+            part = batch[i:i + self.lib.WS_MAX]
+            arr = (self.lib.WsItem * len(part))()
+            for j, (w, o) in enumerate(part):
+                arr[j].w, arr[j].out = w.data_ptr(), o.data_ptr()
+                arr[j].rows, arr[j].cols = w.shape
+            steps.append(self._call("dsc_transpose_batched_f32", arr, len(part), keep=(arr, part)))
+        return steps
+
+    def copy(self, dst, src):
+        dp, ldd = self._mat(dst)
+        sp, lds = self._mat(src)
+        return self._call("dsc_copy2d_f32", dp, ldd, sp, lds, dst.shape[0], dst.shape[1], keep=(dst, src))
+
+    def add(self, dst, src):
+        dp, ldd = self._mat(dst)
+        sp, lds = self._mat(src)
+        return self._call("dsc_add2d_f32", dp, ldd, sp, lds, dst.shape[0], dst.shape[1], keep=(dst, src))
+
+    # -- execution
+    def run(self, steps, stream):
+        check = self.lib.check
+        for st in steps:
+            if isinstance(st, dict):
+                st = st["step"]
+            f, a, name = st
+            rc = f(*a, stream)
+            if rc:
+                check(rc, name)
+
+
+# ======================================================================================================================
+class TrainPlan:
+    """Forward + loss + backward launch lists of one (B, N, conditioning) signature of one Unet1D."""
+
+    def __init__(self, net, flat, diff, B, N, ctx_mode, ctx_dim, L, text_dim, backend, per_block_grads=False,
+                 ctx_param=None, tables=None, grad_scale=None):
+        self.net, self.flat, self.diff = net, flat, diff
+        self.B, self.N, self.M = B, N, B * N
+        self.be = backend
+        self.device = backend.device
+        self.ctx_mode, self.ctx_dim, self.L, self.text_dim = ctx_mode, ctx_dim, L, text_dim
+        self.per_block_grads = per_block_grads
+        self.fwd, self.bwd = [], []
+        self._tape = []
+        self._transposes = []
+        self._cur = self.fwd
+        self.bwd_writes = []              # (index of the LAST step of a backward op, (G offset, length)) per finished gradient
+        self.n_adds = 0
+        C_in = net.channels
+        dev = self.device
+        # ---- static inputs
+        self.x0 = self.new3(B, N, C_in)
+        self.noise = self.new3(B, N, C_in)
+        self.t = torch.zeros((B,), device=dev, dtype=torch.int64)
+        ctx_rows = {SS_NONE: 0, SS_PER_SLOT: N, SS_PER_TOKEN: self.M}[ctx_mode]
+        # ctx_param: the context IS a parameter (learnable instance embedding, shared over the batch): read it in place and
+        # write its gradient straight into G -- no autograd boundary at all for the shipped unconditional configs
+        self.ctx_grad_param = ctx_param
+        if ctx_param is not None:
+            assert ctx_mode == SS_PER_SLOT and tuple(ctx_param.shape) == (N, ctx_dim)
+            self.ctx_in = H(ctx_param.detach())
+        else:
+            self.ctx_in = H(self.new(ctx_rows, ctx_dim)) if ctx_rows else None
+        self.cross_in = H(self.new(B * L, text_dim)) if L else None
+        # ---- outputs
+        self.x_t = self.new3(B, N, C_in)
+        self.out = self.new(self.M, net.out_dim)
+        self.dout = self.new(self.M, net.out_dim)
+        self.losses = torch.zeros((B,), device=dev)
+        self.parts = torch.zeros((B, 9), device=dev)
+        self._tables = tables
+        # loss = losses.mean() over the (global) batch: d loss / d losses[b] = 1/B, or 1/(B * world) when the ranks' gradients
+        # are SUMMED by the all-reduce (the mean over ranks is folded in here instead of a second pass over G)
+        self.grad_scale = 1.0 / B if grad_scale is None else float(grad_scale)
+        self._build()
+        if hasattr(self.be, "finalize"):
+            self.be.finalize()
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def new(self, rows, cols):
+        return torch.empty((rows, cols), device=self.device, dtype=torch.float32)
+
+    def new3(self, a, b, c):
+        return torch.empty((a, b, c), device=self.device, dtype=torch.float32)
+
+    def zeros(self, rows, cols):
+        return torch.zeros((rows, cols), device=self.device, dtype=torch.float32)
+
+    def emit(self, step):
+        if isinstance(step, list):
+            self._cur.extend(step)
+        else:
+            self._cur.append(step)
+
+    def gview(self, p):
+        return _as2d(self.flat.grad_view(p)) if p.dim() != 1 else self.flat.grad_view(p)
+
+    def wrote(self, *params):
+        """Mark parameters whose gradient is final once the steps emitted so far have run."""
+        idx = len(self.bwd) - 1
+        for p in params:
+            if p is not None:
+                self.bwd_writes.append((idx, self.flat.grad_range(p)))
+
+    def wrote_range(self, off, n):
+        self.bwd_writes.append((len(self.bwd) - 1, (off, n)))
+
+    # ------------------------------------------------------------------------------------------------ gradient plumbing
+    @staticmethod
+    def _dense_ok(t):
+        return t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+    # Invariant that makes aliasing safe: a gradient tensor is only ever handed to handles whose backward emitters run
+    # strictly LATER (they belong to earlier forward ops), and every emitter finishes reading its own dy before it hands dy
+    # on.  So accumulating in place into an aliased buffer can never disturb a reader.
+    def g_alias(self, h, src):
+        """grad(h) += src where src is a finished gradient tensor: no copy when it is the first contribution."""
+        if not h.ng:
+            return
+        if h.g is None:
+            h.g = src
+        else:
+            self.emit(self.be.add(h.g, src))
+            self.n_adds += 1
+
+    def g_target(self, h):
+        """-> (tensor to write a [rows, cols] contribution into, accumulate?)."""
+        if h.g is None:
+            h.g = self.new(*h.t.shape)
+            return h.g, False
+        return h.g, True
+
+    def g_write(self, h, produce):
+        """Contribution from a kernel that cannot accumulate: ``produce(dst)`` emits it."""
+        if not h.ng:
+            return
+        if h.g is None:
+            h.g = self.new(*h.t.shape)
+            produce(h.g)
+        else:
+            tmp = self.new(*h.t.shape)
+            produce(tmp)
+            self.emit(self.be.add(h.g, tmp))
+            self.n_adds += 1
+
+    def g_gemm(self, a, a2, dy, wt):
+        """grad([a | a2]) += dy @ wt^T-layout weight (wt is [K, n]: the GEMM computes dy . wt^T)."""
+        k1 = a.t.shape[1]
+        K = wt.shape[0]
+        if a2 is None:
+            if not a.ng:
+                return
+            dst, acc = self.g_target(a)
+            self._gemm_acc(dy, wt, dst, acc)
+            return
+        want1, want2 = a.ng, a2.ng
+        if not (want1 or want2):
+            return
+        pair_fresh = a.g is None and a2.g is None and want1 and want2
+        same_parent = (a.g is not None and a2.g is not None and a.g.stride(0) == K and a2.g.stride(0) == K
+                       and a2.g.data_ptr() == a.g.data_ptr() + 4 * k1)
+        if pair_fresh:
+            buf = self.new(dy.shape[0], K)
+            a.g, a2.g = buf[:, :k1], buf[:, k1:]
+            self._gemm_acc(dy, wt, buf, False)
+        elif same_parent:
+            buf = torch.as_strided(a.g, (a.g.shape[0], K), (K, 1))
+            self._gemm_acc(dy, wt, buf, True)
+        else:
+            tmp = self.new(dy.shape[0], K)
+            self._gemm_acc(dy, wt, tmp, False)
+            if want1:
+                self.g_alias(a, tmp[:, :k1])
+            if want2:
+                self.g_alias(a2, tmp[:, k1:])
+
+    def _gemm_acc(self, dy, wt, dst, acc):
+        n = dy.shape[1]
+        if n > 4096:
+            # long reductions (the packed 19x1024 time-MLP outputs): accumulate in chunks of 2048 so that the fp32 error
+            # stays that of a blocked sum instead of one 19456-term sequential chain
+            for c0 in range(0, n, 2048):
+                c1 = min(c0 + 2048, n)
+                self.emit(self.be.gemm(dy[:, c0:c1], wt[:, c0:c1], dst, residual=dst if (acc or c0 > 0) else None))
+        else:
+            self.emit(self.be.gemm(dy, wt, dst, residual=dst if acc else None))
+
+    def wT(self, w2d, npad=None):
+        """Transposed copy [K, n(pad)] of a weight, refreshed once per step at the start of the backward pass."""
+        n, K = w2d.shape
+        if npad is None or npad == n:
+            buf = self.new(K, n)
+            self._transposes.append((w2d, buf))
+            return buf
+        buf = self.zeros(K, npad)
+        self._transposes.append((w2d, buf[:, :n]))
+        return buf
+
+    # ------------------------------------------------------------------------------------------------ layers
+    def linear(self, a, weight, bias, a2=None, residual=None, out=None, act_out=ACT_NONE, wt=None):
+        """y = [a | a2] @ W^T + b (+ residual).  ``out`` may be a column slice of a wider tensor (decoder heads)."""
+        w2 = _as2d(weight)
+        n, K = w2.shape
+        rows = a.t.shape[0]
+        y = H(out if out is not None else self.new(rows, n))
+        self.emit(self.be.gemm(a.t, w2, y.t, bias, a2.t if a2 is not None else None,
+                               residual.t if residual is not None else None, act_out))
+        assert act_out == ACT_NONE, "training keeps activations as separate ops (their backward needs the pre-activation)"
+
+        def bw():
+            dy = y.g
+            if dy is None:
+                return
+            npad = (n + 31) // 32 * 32
+            if npad != n:
+                dyp = self.zeros(rows, npad)
+                self.emit(self.be.copy(dyp[:, :n], dy))
+            elif not self._dense_ok(dy):
+                dyp = self.new(rows, n)
+                self.emit(self.be.copy(dyp, dy))
+            else:
+                dyp = dy
+            if a.ng or (a2 is not None and a2.ng):
+                self.g_gemm(a, a2, dyp, wt if wt is not None else self.wT(w2, npad))
+            gw = self.gview(weight)
+            gb = self.flat.grad_view(bias) if bias is not None else None
+            if npad != n:
+                tw = self.new(npad, K)
+                tb = self.new(1, npad) if bias is not None else None
+                self.emit(self.be.gemm_tn(a.t, dyp, tw, a2.t if a2 is not None else None,
+                                          dbias=tb.view(-1) if tb is not None else None))
+                self.emit(self.be.copy(gw, tw[:n]))
+                if bias is not None:
+                    self.emit(self.be.copy(gb.view(1, n), tb[:, :n]))
+            else:
+                self.emit(self.be.gemm_tn(a.t, dyp, gw, a2.t if a2 is not None else None, dbias=gb))
+            self.wrote(weight, bias)
+            if residual is not None:
+                self.g_alias(residual, dy)
+        self._tape.append(bw)
+        return y
+
+    def smallk(self, x_slice, weight, bias):
+        """First encoder layer on an un-aligned column slice of x_t (no input gradient)."""
+        w2 = _as2d(weight)
+        n, k = w2.shape
+        rows = x_slice.shape[0]
+        y = H(self.new(rows, n))
+        self.emit(self.be.smallk(x_slice, w2, bias, y.t))
+        xpad = self.zeros(rows, 32 if k <= 32 else 64)
+        self.emit(self.be.copy(xpad[:, :k], x_slice))          # staged for the weight-gradient MFMA pass
+
+        def bw():
+            if y.g is None:
+                return
+            self.emit(self.be.gemm_tn(xpad, y.g, self.gview(weight), kvalid=k, dbias=self.flat.grad_view(bias)))
+            self.wrote(weight, bias)
+        self._tape.append(bw)
+        return y
+
+    def act(self, x, kind):
+        y = H(self.new(*x.t.shape))
+        self.emit(self.be.act(x.t, y.t, kind))
+
+        def bw():
+            if y.g is None or not x.ng:
+                return
+            dy = y.g
+            if not dy.is_contiguous():
+                d = self.new(*dy.shape)
+                self.emit(self.be.copy(d, dy))
+                dy = d
+            self.g_write(x, lambda dst: self.emit(self.be.act_bwd(x.t, dy, dst, kind)))
+        self._tape.append(bw)
+        return y
+
+    def conv_gn(self, a, blk, a2=None, ss=None, ss_mode=SS_NONE, dss=None, residual=None):
+        """Block.forward (:167-176) incl. weight standardisation: one fused GEMM; z = pre-norm output kept for backward."""
+        conv, norm = blk.proj, blk.norm
+        w_std = self.ws_std[id(conv)]
+        rows = a.t.shape[0]
+        y, z = H(self.new(rows, D)), self.new(rows, D)
+        self.emit(self.be.gemm_gn(a.t, w_std, y.t, conv.bias, norm.weight, norm.bias, self.N, a2.t if a2 is not None else None,
+                                  ss, ss_mode, residual.t if residual is not None else None, z))
+
+        def bw():
+            dy = y.g
+            if dy is None:
+                return
+            scenes = rows // self.N
+            dz = self.new(rows, D)
+            part = self.new(scenes, 3 * D)
+            slot_tmp = None
+            dss_arg = dss
+            if ss is not None and ss_mode == SS_PER_SLOT:
+                slot_tmp = self.new(rows, 2 * D)          # per-token, reduced over the batch below
+                dss_arg = slot_tmp
+            self.emit(self.be.gn_bwd(z, dy, norm.weight, norm.bias, ss, ss_mode, dz, part, dss_arg, scenes, self.N))
+            o_b, o_g, o_be = (self.flat.grad_range(p)[0] for p in (conv.bias, norm.weight, norm.bias))
+            if o_g == o_b + D and o_be == o_g + D:
+                self.emit(self.be.colsum(part, self.flat.G[o_b:o_b + 3 * D]))
+            else:
+                tmp = self.new(1, 3 * D)
+                self.emit(self.be.colsum(part, tmp.view(-1)))
+                for i, p in enumerate((conv.bias, norm.weight, norm.bias)):
+                    self.emit(self.be.copy(self.flat.grad_view(p).view(1, D), tmp[:, i * D:(i + 1) * D]))
+            self.wrote(conv.bias, norm.weight, norm.bias)
+            if slot_tmp is not None:
+                red = self.new(self.N, 2 * D)
+                self.emit(self.be.colsum(slot_tmp.view(scenes, self.N * 2 * D), red.view(-1)))
+                self.emit(self.be.copy(dss, red))
+            self.g_gemm(a, a2, dz, self.ws_t[id(conv)])
+            self.emit(self.be.gemm_tn(a.t, dz, self.dws[id(conv)], a2.t if a2 is not None else None))
+            self._ws_pending.append(conv)
+            if residual is not None:
+                self.g_alias(residual, dy)
+        self._tape.append(bw)
+        return y
+
+    def resblock(self, rb, a, a2, ss_pair, post=None):
+        """ResnetBlock.forward (:190-206).  ``post`` is emitted right after the block's backward (the tape runs in reverse, so
+        it is pushed first): data parallelism finishes the block's slices of G there."""
+        if post is not None:
+            self._tape.append(post)
+        ss, mode, dss = ss_pair
+        h = self.conv_gn(a, rb.block1, a2=a2, ss=ss, ss_mode=mode, dss=dss)
+        r = self.linear(a, rb.res_conv.weight, rb.res_conv.bias, a2=a2) if rb.has_res_conv else a
+        return self.conv_gn(h, rb.block2, residual=r)
+
+    def layernorm(self, x, gain, residual=None):
+        g = gain.view(-1)
+        y = H(self.new(*x.t.shape))
+        self.emit(self.be.layernorm(x.t, g, y.t, residual.t if residual is not None else None))
+
+        def bw():
+            dy = y.g
+            if dy is None:
+                return
+            M_ = x.t.shape[0]
+            nblk = min((M_ + 3) // 4, 512)
+            part = self.new(nblk, x.t.shape[1])
+            self.g_write(x, lambda dst: self.emit(self.be.layernorm_bwd(x.t, g, dy, dst, part)))
+            self.emit(self.be.colsum(part, self.flat.grad_view(gain).view(-1)))
+            self.wrote(gain)
+            if residual is not None:
+                self.g_alias(residual, dy)
+        self._tape.append(bw)
+        return y
+
+    def linattn(self, blk, a):
+        att = blk.fn.fn
+        B, N = self.B, self.N
+        y = self.layernorm(a, blk.fn.norm.g)
+        qkv = self.linear(y, att.to_qkv.weight, None)
+        o = H(self.new(self.M, HID))
+        q, k, v = qkv.t[:, :HID], qkv.t[:, HID:2 * HID], qkv.t[:, 2 * HID:]
+        self.emit(self.be.linattn(q, k, v, o.t, B, N, N, float(att.scale)))
+
+        def bw():
+            if o.g is None:
+                return
+            d = self.new(self.M, 3 * HID)
+            qkv.g = d
+            self.emit(self.be.linattn_bwd(q, k, v, o.g, d[:, :HID], d[:, HID:2 * HID], d[:, 2 * HID:], B, N, N,
+                                          float(att.scale)))
+        self._tape.append(bw)
+        p = self.linear(o, att.to_out[0].weight, att.to_out[0].bias)
+        return self.layernorm(p, att.to_out[1].g, residual=a)
+
+    def crossattn(self, blk, a):
+        att = blk.fn.fn
+        B, N, L = self.B, self.N, self.L
+        y = self.layernorm(a, blk.fn.norm.g)
+        qh = self.linear(y, att.to_q.weight, None)
+        kv = self.linear(self.cross_in, att.to_kv.weight, None)
+        o = H(self.new(self.M, HID))
+        self.emit(self.be.linattn(qh.t, kv.t[:, :HID], kv.t[:, HID:], o.t, B, N, L, float(att.scale)))
+
+        def bw():
+            if o.g is None:
+                return
+            dq, dkv = self.new(self.M, HID), self.new(B * L, 2 * HID)
+            qh.g, kv.g = dq, dkv
+            self.emit(self.be.linattn_bwd(qh.t, kv.t[:, :HID], kv.t[:, HID:], o.g, dq, dkv[:, :HID], dkv[:, HID:], B, N, L,
+                                          float(att.scale)))
+        self._tape.append(bw)
+        p = self.linear(o, att.to_out[0].weight, att.to_out[0].bias)
+        return self.layernorm(p, att.to_out[1].g, residual=a)
+
+    def fullattn(self, blk, a):
+        att = blk.fn.fn
+        B, N = self.B, self.N
+        y = self.layernorm(a, blk.fn.norm.g)
+        qkv = self.linear(y, att.to_qkv.weight, None)
+        o = H(self.new(self.M, HID))
+        q, k, v = qkv.t[:, :HID], qkv.t[:, HID:2 * HID], qkv.t[:, 2 * HID:]
+        self.emit(self.be.attn(q, k, v, o.t, B, N, float(att.scale)))
+
+        def bw():
+            if o.g is None:
+                return
+            d = self.new(self.M, 3 * HID)
+            qkv.g = d
+            self.emit(self.be.attn_bwd(q, k, v, o.g, d[:, :HID], d[:, HID:2 * HID], d[:, 2 * HID:], B, N, float(att.scale)))
+        self._tape.append(bw)
+        return self.linear(o, att.to_out.weight, att.to_out.bias, residual=a)
+
+    def encoder(self, seq, c0, k, acc):
+        xf = self.x_t.view(self.M, -1)
+        h = self.act(self.smallk(xf[:, c0:c0 + k], seq[0].weight, seq[0].bias), ACT_GELU)
+        h = self.act(self.linear(h, seq[2].weight, seq[2].bias), ACT_GELU)
+        return self.linear(h, seq[4].weight, seq[4].bias, residual=acc)
+
+    # ------------------------------------------------------------------------------------------------ build
+    def _build(self):
+        net, be, B, N, M = self.net, self.be, self.B, self.N, self.M
+        diff = self.diff
+        tb = self._tables if self._tables is not None else diff.tables(self.device)
+        self.tb = tb
+        fl = self.flat
+        # ---- q_sample + training target (:531-546)
+        want_v = diff.model_mean_type == "v"
+        self.v_buf = self.new3(B, N, net.channels) if want_v else None
+        self.emit(be.q_sample(self.x0, self.noise, self.t, tb["sqrt_alphas_cumprod"], tb["sqrt_one_minus_alphas_cumprod"],
+                              self.x_t, self.v_buf))
+        self.target = {"v": self.v_buf, "eps": self.noise, "x0": self.x0}[diff.model_mean_type]
+        # ---- weight standardisation of all WS-convs: one launch forward, one (or one per block) backward
+        blocks = net.resblocks_in_order()
+        ws_mods = []
+        for rb, _ in blocks:
+            ws_mods += [rb.block1.proj, rb.block2.proj]
+        self.ws_mods = ws_mods
+        self.ws_std = {id(m): self.new(*_as2d(m.weight).shape) for m in ws_mods}
+        self.dws = {id(m): self.new(*_as2d(m.weight).shape) for m in ws_mods}
+        self.ws_t = {id(m): self.new(_as2d(m.weight).shape[1], _as2d(m.weight).shape[0]) for m in ws_mods}
+        self._ws_pending = []
+        self.emit(be.ws([_as2d(m.weight) for m in ws_mods], [self.ws_std[id(m)] for m in ws_mods]))
+        for m in ws_mods:
+            self._transposes.append((self.ws_std[id(m)], self.ws_t[id(m)]))
+        # ---- conditioning
+        t_blocks = [rb for rb, kind in blocks if kind == "t"]
+        c_blocks = [rb for rb, kind in blocks if kind == "c" and rb.mlp is not None]
+        t_index = {id(rb): i for i, rb in enumerate(t_blocks)}
+        c_index = {id(rb): i for i, rb in enumerate(c_blocks)}
+        eng_table = net.time_table.to(self.device)
+        eng_freq = net.time_freq.to(self.device)
+        temb = H(self.new(B, D), needs_grad=False)
+        self.emit(be.time_embedding(self.t, eng_table, eng_freq, temb.t))
+        t1 = self.act(self.linear(temb, net.time_mlp[1].weight, net.time_mlp[1].bias), ACT_GELU)
+        t2 = self.act(self.linear(t1, net.time_mlp[3].weight, net.time_mlp[3].bias), ACT_SILU)
+        tw, tgw = fl.packed["t_w"]
+        tbias, tgb = fl.packed["t_b"]
+        ss_t = H(self.new(B, tw.shape[0]))
+        self.emit(be.gemm(t2.t, tw, ss_t.t, tbias))
+        dss_t = self.new(B, tw.shape[0])
+        ss_t.g = dss_t
+        tw_t = self.wT(tw)
+
+        def bw_time_pack():
+            # every time-conditioned block has written its [B, 1024] slice of dss_t by now
+            self.g_gemm(t2, None, dss_t, tw_t)
+            if self.per_block_grads:
+                return                       # the per-block TN launches were emitted next to each block (bucket overlap)
+            self.emit(be.gemm_tn(t2.t, dss_t, tgw, dbias=tgb))
+            self.wrote_range(*fl.pack_range["t_w"])
+            self.wrote_range(*fl.pack_range["t_b"])
+        self._tape.append(bw_time_pack)
+        self._t_pack = (t2, dss_t, tgw, tgb)
+
+        ss_c = dss_c = None
+        if self.ctx_in is not None and c_blocks:
+            cact = self.act(self.ctx_in, ACT_SILU)
+            cw, cgw = fl.packed["c_w"]
+            cb, cgb = fl.packed["c_b"]
+            ss_c = H(self.new(self.ctx_in.t.shape[0], cw.shape[0]))
+            self.emit(be.gemm(cact.t, cw, ss_c.t, cb))
+            dss_c = self.new(self.ctx_in.t.shape[0], cw.shape[0])
+            ss_c.g = dss_c
+            cw_t = self.wT(cw)
+
+            def bw_ctx_pack():
+                self.g_gemm(cact, None, dss_c, cw_t)
+                self.emit(be.gemm_tn(cact.t, dss_c, cgw, dbias=cgb))
+                self.wrote_range(*fl.pack_range["c_w"])
+                self.wrote_range(*fl.pack_range["c_b"])
+            self._tape.append(bw_ctx_pack)
+
+        def t_ss(rb):
+            i = t_index[id(rb)]
+            sl = slice(i * 2 * D, (i + 1) * 2 * D)
+            return ss_t.t[:, sl], SS_PER_SCENE, dss_t[:, sl]
+
+        def c_ss(rb):
+            if ss_c is None:
+                return None, SS_NONE, None
+            i = c_index[id(rb)]
+            sl = slice(i * 2 * D, (i + 1) * 2 * D)
+            return ss_c.t[:, sl], self.ctx_mode, dss_c[:, sl]
+
+        def cblock(rb, a):
+            return self.resblock(rb, a, None, c_ss(rb), post=self._flush_ws_pending if self.per_block_grads else None)
+
+        def tb_(rb, a, a2=None):
+            post = None
+            if self.per_block_grads:
+                i = t_index[id(rb)]
+                sl = slice(i * 2 * D, (i + 1) * 2 * D)
+
+                def post(i=i, sl=sl):
+                    # data parallel: this block's rows of the packed time-MLP gradient right after the block's backward, so
+                    # that the bucket holding them can be all-reduced while the rest of the backward runs
+                    self._flush_ws_pending()
+                    self.emit(be.gemm_tn(t2.t, dss_t[:, sl], tgw[sl], dbias=tgb[sl]))
+                    o, _ = fl.pack_range["t_w"]
+                    self.wrote_range(o + i * 2 * D * tw.shape[1], 2 * D * tw.shape[1])
+                    ob, _ = fl.pack_range["t_b"]
+                    self.wrote_range(ob + i * 2 * D, 2 * D)
+            return self.resblock(rb, a, a2, t_ss(rb), post=post)
+
+        # ---- input embedding
+        xf = self.x_t.view(M, -1)
+        if net.seperate_all:
+            bb, nc, no, nf = net.bbox_dim, net.class_dim, net.objectness_dim, net.objfeat_dim
+            e = self.encoder(net.class_embedf, bb, nc, None)
+            e = self.encoder(net.bbox_embedf, 0, bb, e)
+            if no > 0:
+                e = self.encoder(net.objectness_embedf, bb + nc, no, e)
+            if nf > 0:
+                e = self.encoder(net.objfeat_embedf, bb + nc + no, nf, e)
+            h = self.linear(e, net.init_conv.weight, net.init_conv.bias)
+        else:
+            h = self.smallk(xf, net.init_conv.weight, net.init_conv.bias)
+        r = h
+        skips = []
+        text = net.text_condition and self.cross_in is not None
+
+        for lvl in net.downs:
+            b0, b1, ac, b2, la, down = lvl
+            h = cblock(b0, h)
+            h = tb_(b1, h)
+            skips.append(h)
+            if text:
+                h = self.crossattn(ac, h)
+            h = tb_(b2, h)
+            h = self.linattn(la, h)
+            skips.append(h)
+            if isinstance(down, torch.nn.Conv1d):
+                h = self.linear(h, down.weight, down.bias)
+        h = cblock(net.mid_block0, h)
+        h = tb_(net.mid_block1, h)
+        if text:
+            h = self.crossattn(net.mid_attn_cross, h)
+        h = self.fullattn(net.mid_attn, h)
+        h = tb_(net.mid_block2, h)
+        for lvl in net.ups:
+            b0, b1, ac, b2, la, up = lvl
+            h = cblock(b0, h)
+            h = tb_(b1, h, skips.pop())
+            if text:
+                h = self.crossattn(ac, h)
+            h = tb_(b2, h, skips.pop())
+            h = self.linattn(la, h)
+            if isinstance(up, torch.nn.Conv1d):
+                h = self.linear(h, up.weight, up.bias)
+        h = tb_(net.final_res_block, h, r)
+        # ---- output heads, written straight into the (M, C) output at their column offsets
+        self.head_outs = []
+        if net.seperate_all:
+            heads = [(net.bbox_hidden2output, net.bbox_dim), (net.class_hidden2output, net.class_dim)]
+            if net.objectness_dim > 0:
+                heads.append((net.objectness_hidden2output, net.objectness_dim))
+            if net.objfeat_dim > 0:
+                heads.append((net.objfeat_hidden2output, net.objfeat_dim))
+            col = 0
+            for seq, width in heads:
+                d1 = self.act(self.linear(h, seq[0].weight, seq[0].bias), ACT_GELU)
+                d2 = self.act(self.linear(d1, seq[2].weight, seq[2].bias), ACT_GELU)
+                o = self.linear(d2, seq[4].weight, seq[4].bias, out=self.out[:, col:col + width])
+                o.g = self.dout[:, col:col + width]
+                self.head_outs.append(o)
+                col += width
+        else:
+            o = self.linear(h, net.final_conv.weight, net.final_conv.bias, out=self.out)
+            o.g = self.dout
+            self.head_outs.append(o)
+        # ---- loss + d loss / d out (loss = losses.mean() -> grad_scale 1/B)
+        from . import ops
+        ca, cb_ = diff._coeffs(tb)
+        arrange = bool(getattr(diff, "room_arrange_condition", False))
+        if arrange:
+            dims = dict(translation_dim=diff.translation_dim, size_dim=0, bbox_dim=net.channels, class_dim=0,
+                        objectness_dim=0, objfeat_dim=0)
+            iou, bounds = False, None
+        else:
+            dims = dict(translation_dim=diff.translation_dim, size_dim=diff.size_dim, bbox_dim=diff.bbox_dim,
+                        class_dim=diff.class_dim, objectness_dim=diff.objectness_dim, objfeat_dim=diff.objfeat_dim)
+            iou = bool(diff.loss_iou)
+            bounds = (list(diff._centroids[0]) + list(diff._centroids[1]) + list(diff._sizes[0]) + list(diff._sizes[1])) \
+                if iou else None
+        mean_type = {"eps": ops.MEAN_EPS, "x0": ops.MEAN_X0, "v": ops.MEAN_V}[diff.model_mean_type]
+        self.n_fwd_only = len(self.fwd)
+        self.emit(be.loss(self.target, self.out.view(B, N, -1), self.x_t, self.t, tb, ca, cb_, bounds, dims,
+                          bool(diff.loss_separate), iou, mean_type, self.losses, self.parts, self.dout.view(B, N, -1),
+                          self.grad_scale))
+        self._build_backward()
+
+    def _build_backward(self):
+        be = self.be
+        self._cur = self.bwd
+        assert not self.bwd
+        self._ws_flushed = 0
+        for f in reversed(self._tape):
+            f()
+        self._flush_ws_pending()                      # single GPU: all 56 weight-standardisation backwards in one launch
+        # context gradient of a parameter-backed context (learnable instance embedding): straight into G
+        if self.ctx_in is not None and self.ctx_grad_param is not None and self.ctx_in.g is not None:
+            self.emit(be.copy(self.gview(self.ctx_grad_param), self.ctx_in.g))
+            self.wrote(self.ctx_grad_param)
+        # the transposes of this step's weights run first; they were registered while the emitters ran
+        body = self.bwd
+        self.bwd = []
+        self._cur = self.bwd
+        self.emit(be.transpose_many(self._transposes))
+        shift = len(self.bwd)
+        self.bwd.extend(body)
+        self.bwd_writes = [(i + shift, r) for i, r in self.bwd_writes]
+        self.d_ctx = self.ctx_in.g if self.ctx_in is not None else None
+        self.d_cross = self.cross_in.g if self.cross_in is not None else None
+
+    def _flush_ws_pending(self):
+        convs = self._ws_pending[self._ws_flushed:]
+        if not convs:
+            return
+        self._ws_flushed = len(self._ws_pending)
+        ws = [_as2d(m.weight) for m in convs]
+        self.emit(self.be.ws_bwd(ws, [self.dws[id(m)] for m in convs], [self.gview(m.weight) for m in convs]))
+        self.wrote(*[m.weight for m in convs])
+
+    # ------------------------------------------------------------------------------------------------ run
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+
+    def run_forward(self, with_loss=True):
+        self.be.run(self.fwd if with_loss else self.fwd[:self.n_fwd_only], self.stream())
+
+    def run_backward(self, on_progress=None):
+        """Enqueue the backward launches; ``on_progress(i)`` is called after launch ``i`` has been enqueued (the data-parallel
+        reducer uses it to start the all-reduce of finished buckets)."""
+        if on_progress is None:
+            self.be.run(self.bwd, self.stream())
+            return
+        s = self.stream()
+        for i in range(len(self.bwd)):
+            self.be.run(self.bwd[i:i + 1], s)
+            on_progress(i)
+
+    def bucket_schedule(self, buckets):
+        """For contiguous G ranges [(start, end)]: {launch index: [bucket ids finished by that launch]}; buckets nothing
+        in the plan writes (wrapper-level parameters) are returned under the key None."""
+        last = [None] * len(buckets)
+        for idx, (off, n) in self.bwd_writes:
+            for b, (s, e) in enumerate(buckets):
+                if off < e and off + n > s:
+                    last[b] = idx if last[b] is None else max(last[b], idx)
+        sched = {}
+        for b, idx in enumerate(last):
+            sched.setdefault(idx, []).append(b)
+        return sched

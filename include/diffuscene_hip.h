@@ -208,14 +208,21 @@ int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t l
  * one kernel, one block per scene: separated MSE terms x loss_weight[t] + the masked pairwise 3-D IoU regulariser
  * (loss.py:7-102) on the clamped, de-normalised x0 estimate  x0 = ca[t]*x_t - cb[t]*out  (mean_type v / eps; out itself
  * for x0).  losses[b] = losses_weight of scene b; parts[b][9] = {bbox, trans, size, angle, class, object, objfeat,
- * liou, bbox_iou}; dout[b] = d losses[b] / d out[b].  bounds is a HOST array {centroid min[3], max[3], size min[3],
+ * liou, bbox_iou}; dout[b] = grad_scale * d losses[b] / d out[b] (grad_scale = 1/B for loss = losses.mean()).  The
+ * re-arrangement model (:558-571; size_dim = class_dim = objectness_dim = objfeat_dim = 0, c = bbox_dim = translation +
+ * angle channels) uses losses = l_trans + l_angle, no IoU term.  bounds is a HOST array {centroid min[3], max[3], size min[3],
  * max[3]} (dataset_stats.txt, :137-151), required when loss_iou. */
 int dsc_ddpm_loss_f32(const float* target, const float* out, const float* x_t, const int64_t* t,
                       const float* loss_weight, const float* ca, const float* cb, const float* alphas_cumprod,
                       const float* bounds, float* losses, float* parts, float* dout, int32_t b, int32_t n, int32_t c,
                       int32_t translation_dim, int32_t size_dim, int32_t bbox_dim, int32_t class_dim,
                       int32_t objectness_dim, int32_t objfeat_dim, int32_t loss_separate, int32_t loss_iou,
-                      int32_t mean_type, dsc_stream_t stream);
+                      int32_t mean_type, float grad_scale, dsc_stream_t stream);
+
+/* Strided 2-D copy / accumulate (static training plan: staging of un-aligned column slices, gradient accumulation of
+ * multi-consumer activations such as skip connections):  dst[r][c] = src[r][c]   /   dst[r][c] += src[r][c]. */
+int dsc_copy2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, int32_t cols, dsc_stream_t stream);
+int dsc_add2d_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, int32_t cols, dsc_stream_t stream);
 
 /* dx = dy * act'(x) */
 int dsc_activation_bwd_f32(const float* x, const float* dy, float* dx, int64_t count, int32_t act, dsc_stream_t stream);

@@ -2,6 +2,7 @@
 fused clip -- reproduces the single-process gradient on the concatenated batch."""
 import os
 import socket
+import sys
 
 import torch
 import torch.distributed as dist
@@ -82,3 +83,107 @@ def test_ddp_mean_gradients_match_single_process(tmp_path):
     assert torch.allclose(got["norm"], ref_norm, rtol=1e-5)
     assert torch.allclose(got["grad"], ref, rtol=1e-5, atol=1e-8)
     assert ddp.world() == 1 and ddp.average_gradients(m) == 0   # no-op when not distributed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the product path: static training plan + flat gradient buffer + FlatGradientReducer (world_size 2, gloo).  The plan is
+# lowered by the CPU backend of tests/plan_sim.py; everything else (flat storage, bucket schedule, in-place all-reduce
+# launched from the backward's progress callback, parameter broadcast, 1/world folded into the loss gradient) is the product.
+# ---------------------------------------------------------------------------------------------------------------------
+def _plan_setup(B, N, seed, tmp, grad_scale, per_block):
+    import contextlib
+    import io
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from plan_sim import SimBackend
+    from oracle import weights as W
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.train_plan import TrainPlan
+    from diffuscene_amd._lib import SS_PER_SLOT
+    kw = dict(W.UNCOND_BEDROOM)
+    stats = os.path.join(tmp, "stats_%d.txt" % os.getpid())
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet1D(**kw)
+        net.load_state_dict(W.synth_state_dict(kw, seed=seed))
+        dp = DiffusionPoint(net, dict(objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32), time_num=1000,
+                            model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=stats)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.positional_embedding = torch.nn.Parameter(W.synth_condition(1, N, 128, seed)[0].clone())
+            self.net = net
+    holder = Holder()
+    flat = FlatStorage(holder)
+    tb = {n: getattr(dp.diffusion, n) for n in dp.diffusion._TABLE_NAMES}
+
+    def make_plan():
+        return TrainPlan(net, flat, dp.diffusion, B, N, SS_PER_SLOT, 128, 0, 0, SimBackend(), per_block_grads=per_block,
+                         ctx_param=holder.positional_embedding, tables=tb, grad_scale=grad_scale)
+    return holder, flat, make_plan
+
+
+def _plan_inputs(Bg, N):
+    from oracle import weights as W
+    x0 = W.synth_scene_batch(Bg, N, 22, 32, seed=11)
+    noise = W.synth_noise((Bg, N, 62), 12)
+    t = torch.tensor([5, 300, 650, 999])[:Bg]
+    return x0, noise, t
+
+
+def _plan_worker(rank, ws, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    torch.set_num_threads(2)
+    from diffuscene_amd import ddp
+    Bg, N = 4, 5
+    Bl = Bg // ws
+    # ranks start from DIFFERENT weights: broadcast_parameters must make them identical
+    holder, flat, make_plan = _plan_setup(Bl, N, seed=rank, tmp=tmp, grad_scale=1.0 / Bg, per_block=True)
+    ddp.broadcast_parameters(holder)
+    plan = make_plan()
+    red = ddp.FlatGradientReducer(flat, plan, n_buckets=8)
+    x0, noise, t = _plan_inputs(Bg, N)
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    plan.x0.copy_(x0[sl]); plan.noise.copy_(noise[sl]); plan.t.copy_(t[sl])
+    for p in flat.params:                      # every gradient must be WRITTEN by the plan (alignment gaps of G stay 0)
+        flat.grad_view(p).fill_(float("nan"))
+    plan.run_forward()
+    plan.run_backward(on_progress=red.on_progress)
+    n = red.finish()
+    assert n == len(red.buckets) >= 8
+    assert red.launched_during_backward >= 5, red.launched_during_backward     # overlapped with the backward
+    assert torch.isfinite(flat.G).all()
+    if rank == 0:
+        torch.save({"G": flat.G.clone(), "P": flat.P.clone(), "order": red.last_order,
+                    "losses": plan.losses.clone()}, os.path.join(tmp, "plan_r0.pt"))
+    else:
+        torch.save({"P": flat.P.clone()}, os.path.join(tmp, "plan_r1.pt"))
+    dist.destroy_process_group()
+
+
+def test_flat_reducer_with_training_plan_matches_single_process(tmp_path):
+    tmp = str(tmp_path)
+    mp.spawn(_plan_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp, "plan_r0.pt")), torch.load(os.path.join(tmp, "plan_r1.pt"))
+    assert torch.equal(r0["P"], r1["P"]), "broadcast_parameters must leave identical replicas"
+    # buckets leave in the order the backward finishes them (decoder heads / last blocks first), the first bucket (wrapper-level
+    # parameters, context MLPs, encoders) last
+    assert r0["order"][-1] == 0 and r0["order"] != sorted(r0["order"]), r0["order"]
+    # single process, whole batch
+    Bg, N = 4, 5
+    holder, flat, make_plan = _plan_setup(Bg, N, seed=0, tmp=tmp, grad_scale=1.0 / Bg, per_block=False)
+    plan = make_plan()
+    x0, noise, t = _plan_inputs(Bg, N)
+    plan.x0.copy_(x0); plan.noise.copy_(noise); plan.t.copy_(t)
+    plan.run_forward()
+    plan.run_backward()
+    assert torch.equal(flat.P, r0["P"])
+    assert torch.allclose(plan.losses[:2], r0["losses"], rtol=1e-5, atol=1e-7)
+    err = float((flat.G - r0["G"]).norm() / flat.G.norm())
+    assert err < 1e-5, err

@@ -1,0 +1,134 @@
+"""Dataflow of the static training plan (diffuscene_amd/train_plan.py) checked on the CPU: the plan is lowered by the torch
+backend of tests/plan_sim.py and every parameter gradient it leaves in the flat buffer G is compared with torch.autograd over
+the oracle (evaluated in float64).  Kernel numerics are covered by the GPU tests; this test pins WHICH buffers each launch
+reads/writes, the accumulation of multi-consumer gradients and the slices of G."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import ref_torch as R          # noqa: E402
+from oracle import weights as W            # noqa: E402
+
+
+def _build(kw, N, tmp_path, arrange=False, ctx_dim=128):
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    import contextlib
+    import io
+    stats = os.path.join(str(tmp_path), "dataset_stats.txt")
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet1D(**kw)
+        sd = W.synth_state_dict(kw)
+        net.load_state_dict(sd)
+        cfg = dict(objectness_dim=0, class_dim=kw["class_dim"], angle_dim=2, objfeat_dim=32, room_arrange_condition=arrange)
+        dp = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=not arrange,
+                            train_stats_file=stats)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.positional_embedding = torch.nn.Parameter(W.synth_condition(1, N, ctx_dim, 0)[0].clone())
+            self.net = net
+    return Holder(), dp.diffusion, sd
+
+
+def _oracle_grads(sd, kw, diff_cfg, x0, t, noise, cond, cross, arrange):
+    """fp64 autograd over the oracle: loss = losses.mean(); returns {name: grad}, d cond, d cross, losses"""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        cond64 = cond.double().requires_grad_(True)
+        cross64 = cross.double().requires_grad_(True) if cross is not None else None
+        tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+        den = lambda xt, tt: R.unet1d_forward(sd64, kw, xt, tt, cond64, cross64)       # noqa: E731
+        if arrange:
+            lw, _ = R.p_losses_arrange(tb, den, x0.double(), t, noise.double())
+        else:
+            lw, _, _ = R.p_losses(tb, den, x0.double(), t, noise.double(), R.dims_from_kwargs(kw), True, True, W.DATASET_STATS)
+        lw.mean().backward()
+        return ({k: v.grad for k, v in sd64.items()}, cond64.grad, cross64.grad if cross64 is not None else None,
+                lw.detach())
+    finally:
+        torch.set_default_dtype(old)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("case", ["uncond_slot", "text_token", "arrange_token", "uncond_slot_ddp"])
+def test_plan_gradients_match_autograd(case, tmp_path):
+    from plan_sim import SimBackend
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.train_plan import TrainPlan
+    from diffuscene_amd._lib import SS_PER_SLOT, SS_PER_TOKEN
+    torch.manual_seed(0)
+    B, N = 3, 6
+    arrange = case.startswith("arrange")
+    text = case.startswith("text")
+    kw = dict(W.REARRANGE_LIVING if arrange else (W.TEXT_BEDROOM if text else W.UNCOND_BEDROOM))
+    ctx_dim = 512 if arrange else 128
+    holder, diff, sd = _build(kw, N, tmp_path, arrange=arrange, ctx_dim=ctx_dim)
+    flat = FlatStorage(holder)
+    assert flat.valid()
+    tb = {n: getattr(diff, n) for n in diff._TABLE_NAMES}
+    slot = case.startswith("uncond_slot")
+    L = 5 if text else 0
+    plan = TrainPlan(holder.net, flat, diff, B, N, SS_PER_SLOT if slot else SS_PER_TOKEN, ctx_dim, L, 512 if text else 0,
+                     SimBackend(), per_block_grads=case.endswith("ddp"),
+                     ctx_param=holder.positional_embedding if slot else None, tables=tb)
+    C = kw["channels"]
+    if arrange:
+        x0 = torch.rand(B, N, C) * 2 - 1
+    else:
+        x0 = W.synth_scene_batch(B, N, kw["class_dim"], 32, seed=3)
+    noise = W.synth_noise((B, N, C), 5)
+    t = torch.tensor([17, 400, 980])
+    if slot:
+        cond = holder.positional_embedding.detach()[None].expand(B, N, ctx_dim)
+    else:
+        cond = W.synth_condition(B, N, ctx_dim, 1, shared=False) if ctx_dim == 128 else torch.randn(B, N, ctx_dim)
+        plan.ctx_in.t.copy_(cond.reshape(B * N, ctx_dim))
+    cross = None
+    if text:
+        cross = W.synth_text_condition(B, L, 512, 2)
+        plan.cross_in.t.copy_(cross.reshape(B * L, 512))
+    plan.x0.copy_(x0); plan.noise.copy_(noise); plan.t.copy_(t)
+    flat.G.fill_(float("nan"))                 # every gradient must be WRITTEN by the plan, not accumulated
+    plan.run_forward()
+    plan.run_backward()
+
+    ref, dcond, dcross, lw = _oracle_grads(sd, kw, None, x0, t, noise, cond, cross, arrange)
+    assert _rel(plan.losses, lw) < 1e-5
+    bad = []
+    for name, p in holder.net.named_parameters():
+        g = flat.grad_view(p)
+        assert torch.isfinite(g).all(), "gradient of %s was not written" % name
+        r = _rel(g.reshape(-1), ref[name].reshape(-1))
+        if r > 2e-4:
+            bad.append((name, r))
+    assert not bad, bad[:10]
+    if slot:
+        # shared instance embedding: d cond summed over the batch lands in the parameter's slice of G
+        assert _rel(flat.grad_view(holder.positional_embedding), dcond.sum(0)) < 2e-4
+    else:
+        assert _rel(plan.d_ctx, dcond.reshape(B * N, ctx_dim)) < 2e-4
+    if text:
+        assert _rel(plan.d_cross, dcross.reshape(B * L, 512)) < 2e-4
+    # bucket schedule: every bucket of G is finished by exactly one launch index (or by the autograd side: key None)
+    buckets = flat.buckets(8)
+    sched = plan.bucket_schedule(buckets)
+    assert sorted(b for bs in sched.values() for b in bs) == list(range(len(buckets)))
+    if case.endswith("ddp"):
+        idx = [i for i in sched if i is not None]
+        assert len(set(idx)) >= 4, "per-block gradients should finish buckets at different points of the backward"
