@@ -185,3 +185,90 @@ def test_fused_adam_is_a_torch_adam_with_the_same_checkpoint_format():
     with pytest.raises(NotImplementedError):
         FusedAdam(ps, amsgrad=True)
     assert isinstance(optimizer_factory({"optimizer": "SGD"}, ps), torch.optim.SGD)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# drop-in surface against the reference's own YAML configs (tests/golden/reference_configs.json, made by
+# tests/golden/make_config_fixture.py from /root/reference/config/**) and the flat parameter storage
+# ---------------------------------------------------------------------------------------------------------------------
+def _ref_configs(golden_dir):
+    import json
+    import os
+    return json.load(open(os.path.join(golden_dir, "reference_configs.json")))
+
+
+def test_build_network_accepts_every_reference_yaml(golden_dir, tmp_path):
+    import contextlib
+    import copy
+    import io
+    import json
+    from oracle import weights as W
+    from diffuscene_amd.networks import build_network, optimizer_factory, schedule_factory, adjust_learning_rate
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    cfgs = _ref_configs(golden_dir)
+    assert len(cfgs) == 12
+    for name, cfg in cfgs.items():
+        config = copy.deepcopy(cfg)
+        config["network"]["diffusion_kwargs"]["train_stats_file"] = str(stats)
+        if config["network"].get("text_condition"):
+            config["network"]["text_bert_cached"] = True          # no BERT weights offline: cached-feature input instead
+        nc = config["network"]["class_dim"]
+        with contextlib.redirect_stdout(io.StringIO()):
+            net, train_fn, val_fn = build_network(8 + nc, nc + 1, config, None, device="cpu")
+            opt = optimizer_factory(config["training"], filter(lambda p: p.requires_grad, net.parameters()))
+            sched = schedule_factory(config["training"])
+        adjust_learning_rate(sched, opt, 0)
+        assert opt.param_groups[0]["lr"] == config["training"]["lr"], name
+        n_params = sum(p.numel() for p in net.parameters())
+        assert 74e6 < n_params < 81e6, (name, n_params)
+        assert callable(train_fn) and callable(val_fn)
+        keys = set(net.state_dict().keys())
+        assert "positional_embedding" in keys and any(k.startswith("diffusion.model.downs.0.0.block1.proj") for k in keys)
+        if "rearrange" in name:
+            assert any(k.startswith("fc_arrange_condition.") for k in keys) and net.diffusion.model.channels == 5
+        if "text" in name:
+            assert "fc_text_f.weight" in keys and net.diffusion.model.text_condition
+
+
+def test_flat_storage_keeps_module_semantics():
+    import contextlib
+    import io
+    import torch
+    from oracle import weights as W
+    from diffuscene_amd.flat import FlatStorage, ensure_flat
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet1D(**dict(W.UNCOND_BEDROOM))
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    fs = FlatStorage(net)
+    assert fs.valid() and ensure_flat(net) is fs
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd0[k]), k                      # values and names unchanged
+    n = sum(p.numel() for p in net.parameters())
+    assert n <= fs.numel < n + 64 * len(fs.params)
+    # packed conditioning weights are views: 19 time-MLP blocks x (1024, 2048), in block order
+    tw, tgw = fs.packed["t_w"]
+    t_blocks = [rb for rb, kind in net.resblocks_in_order() if kind == "t"]
+    assert tw.shape == (19 * 1024, 2048) and tgw.shape == tw.shape
+    for i, rb in enumerate(t_blocks):
+        assert rb.mlp[1].weight.data_ptr() == tw[i * 1024].data_ptr()
+        assert rb.mlp[1].weight.grad.data_ptr() == tgw[i * 1024].data_ptr()
+    # in-place updates (optimizers, load_state_dict) keep the views; zero_grad(set_to_none) is undone by attach_grads
+    net.load_state_dict(W.synth_state_dict(dict(W.UNCOND_BEDROOM)))
+    assert fs.valid()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.zero_grad()
+    assert net.init_conv.weight.grad is None
+    fs.attach_grads()
+    fs.G.fill_(1.0)
+    opt.step()
+    assert fs.valid() and float(net.init_conv.bias.grad.sum()) == 512.0
+    # buckets: contiguous cover of G, cut at parameter boundaries
+    b = fs.buckets(8)
+    assert b[0][0] == 0 and b[-1][1] == fs.numel and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1)) and len(b) >= 8
+    starts = {fs.offset[id(p)] for p in fs.params}
+    assert all(s in starts for s, _ in b)
+    # moving the module invalidates the storage and ensure_flat rebuilds it
+    net.init_conv.weight.data = net.init_conv.weight.data.clone()
+    assert not fs.valid() and ensure_flat(net) is not fs

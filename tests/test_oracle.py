@@ -146,3 +146,49 @@ def test_variational_bound_terms_match_reference(golden_dir):
         r = R.calc_bpd_loop(tb20, den, x, seq, True)
     for a, b in zip(r, g["all_kl"]):
         assert abs(float(a) - b) <= 1e-4 * abs(b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json shapes (tests/golden/wide.npz, real reference outputs from oracle/make_golden_wide.py): N=80 forward and
+# training loss, completion with P=20 given objects, 5-channel re-arrangement at N=80, L=32 text tokens, trajectory
+# ---------------------------------------------------------------------------------------------------------------------
+def test_oracle_at_baseline_shapes_matches_reference(golden_dir):
+    from oracle.make_golden_wide import wide_inputs
+    g = np.load(os.path.join(golden_dir, "wide.npz"))
+    kw, x, t, cond, _ = wide_inputs("living80")
+    sd = W.synth_state_dict(kw)
+    B, N, C = x.shape
+    with torch.no_grad():
+        assert _rel(R.unet1d_forward(sd, kw, x, t, cond, None), g["living80.forward"]) < RTOL
+        tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+        noise = W.synth_noise(tuple(x.shape), 40, "train_noise")
+        lw, scal, _ = R.p_losses(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None), x, t, noise,
+                                 R.dims_from_kwargs(kw), loss_separate=True, loss_iou=True, stats=W.DATASET_STATS)
+        assert _rel(lw, g["living80.losses"]) < RTOL
+        for k, v in scal.items():
+            ref = float(g["living80." + k])
+            assert abs(float(v) - ref) <= RTOL * max(1.0, abs(ref)), k
+        # completion N=80, P=20, T=50
+        tb50 = R.schedule_tables(1e-4, 0.02, 50, "v")
+        shapes = [(B, N, C)]
+        for _ in range(50):
+            shapes += [(B, 20, C), (B, N, C)]
+        s = R.p_sample_loop_complete(tb50, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None), (B, N, C),
+                                     noise_list(shapes, 41, "complete80_"), 50, x[:, :20, :].contiguous(), True)
+        assert _rel(s, g["complete80.T50"]) < 1e-4
+        # text, L=32
+        kwt, xt_, tt_, condt, crosst = wide_inputs("text32")
+        sdt = W.synth_state_dict(kwt)
+        assert _rel(R.unet1d_forward(sdt, kwt, xt_, tt_, condt, crosst), g["text32.forward"]) < RTOL
+        # trajectory: x_T, then the states after t = 49 (first step), 40, 30, 20, 10, 0
+        kwb = W.UNCOND_BEDROOM
+        sdb = W.synth_state_dict(kwb)
+        condb = W.synth_condition(2, 12, 128, 0).contiguous()
+        seq = noise_list([(2, 12, 62)] * 51, 44, "traj_")
+        img, imgs = seq[0], [seq[0]]
+        for i, tt in enumerate(reversed(range(50))):
+            t_ = torch.full((2,), tt, dtype=torch.int64)
+            img = R.p_sample_step(tb50, img, t_, R.unet1d_forward(sdb, kwb, img, t_, condb, None), seq[i + 1], True, "v")
+            if tt % 10 == 0 or tt == 49:
+                imgs.append(img)
+        assert _rel(torch.stack(imgs), g["traj.T50"]) < 1e-4
