@@ -55,7 +55,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     constexpr int STAGE = (BM + BN) * LDT;
     constexpr bool XFULL = (XTOT % T) == 0, WFULL = (WTOT % T) == 0;
 
-    constexpr int EPI = (BN / 32) * BM + 512 + NW * 32 * 36;      // epilogue scratch: GroupNorm partials + per-wave patches
+    // epilogue scratch: GroupNorm partials (sum + centred sum of squares) | stats + row tables | staged (scale, shift) rows of
+    // up to SSL_MAX scenes | per-wave transpose patches
+    constexpr int SSL_MAX = 8;
+    constexpr int EPI = (GN ? 2 * (BN / 32) * BM + 512 + SSL_MAX * 2 * BN : (BN / 32) * BM + 512) + NW * 32 * 36;
     constexpr int SMEM = ((DB ? 2 : 1) * STAGE > EPI) ? (DB ? 2 : 1) * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     const bool fast = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (col0 + BN <= p.n) &&
                       (!res || rfast);
     constexpr int TLD = 36;
-    constexpr int SCR = (BN / 32) * BM + 512;                // GroupNorm scratch (P + stats, N >= 4) lives below the patches
+    constexpr int SCR = GN ? 2 * (BN / 32) * BM + 512 + SSL_MAX * 2 * BN : (BN / 32) * BM + 512;   // scratch below the patches
     static_assert(SCR + NW * 32 * TLD <= SMEM, "epilogue scratch must fit in the LDS allocation");
     float* patch = smem + SCR + wave * (32 * TLD);
     const int tr = lane >> 3, cq = lane & 7;
@@ -316,29 +319,53 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     if constexpr (GN) {
         constexpr int G = BN / 64;        // GroupNorm groups covered by this block
         constexpr int CT = BN / 32;       // 32-channel tiles in the block
-        float* P = smem;                  // [CT][BM] per-token partial sums
-        float* stat = smem + CT * BM;     // [spt*G] mean, then [spt*G] rstd
+        float* P = smem;                  // [CT][BM] per-token sums over the 32 channels of a tile
+        float* Q = smem + CT * BM;        // [CT][BM] per-token sums of squares about the token's own mean
+        float* stat = smem + 2 * CT * BM; // [spt*G] mean, then [spt*G] rstd  (spt * G <= 80 for N >= 4)
+        float* ssl = stat + 512;          // [scenes][2][BN] staged (scale, shift) rows (conditioning shared by a scene)
         const int spt = BM / N;
         const int scenes_here = rows_here / N;
         const int nstat = scenes_here * G;
         const float inv_cnt = 1.0f / (64.0f * (float)N);
-        int scn[TM];
+        const int64_t scene0 = (int64_t)rb * spt;             // blocks are scene-aligned
+        const bool has_ss = p.scale_shift != nullptr;
+        // (scale, shift) of time-conditioned blocks is one row per scene: stage the block's rows in LDS now (the loads fly
+        // during the statistics) instead of gathering them row by row between the output stores -- the compiler cannot hoist
+        // those gathers over the stores (possible aliasing), which serialised one L2 round trip per 8 output rows
+        const bool ss_lds = has_ss && (p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX) && scenes_here <= SSL_MAX;
+        float ssv[SSL_MAX * 2 * BN / T > 0 ? SSL_MAX * 2 * BN / T : 1];
+        if (ss_lds) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int tl = (wm * TM + tm) * 32 + l31;
-            scn[tm] = tl / N;
+            for (int j = 0; j < SSL_MAX * 2 * BN / T; ++j) {
+                const int f = tid + T * j;                     // (scene, half, column) flattened
+                const int sc = f / (2 * BN), hc = f % (2 * BN);
+                if (sc < scenes_here) {
+                    const int64_t row = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + sc : p.ss_index[scene0 + sc];
+                    ssv[j] = p.scale_shift[row * p.ld_ss + (hc >= BN ? p.n : 0) + col0 + (hc % BN)];
+                }
+            }
         }
-        // pass 1: mean
+        // One pass over the accumulators (Chan's pairwise update): every lane reduces its 16 channels to (sum, centred sum
+        // of squares), the two lane halves are merged, then one wave per (scene, group) merges the 2N token entries about
+        // their common mean.  No E[x^2] - E[x]^2 cancellation anywhere: same quality as mean-then-variance, half the passes.
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int tl = (wm * TM + tm) * 32 + l31;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                float s = 0.f;
+                float s16 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += acc[tm][tn][r];
-                s += __shfl_xor(s, 32, 64);
-                if (half == 0) P[(wn * TN + tn) * BM + tl] = s;
+                for (int r = 0; r < 16; ++r) s16 += acc[tm][tn][r];
+                const float m16 = s16 * (1.0f / 16.0f);
+                float q16 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = acc[tm][tn][r] - m16; q16 += d * d; }
+                const float so = __shfl_xor(s16, 32, 64), qo = __shfl_xor(q16, 32, 64);
+                const float dm = (so - s16) * (1.0f / 16.0f);
+                if (half == 0) {
+                    P[(wn * TN + tn) * BM + tl] = s16 + so;
+                    Q[(wn * TN + tn) * BM + tl] = q16 + qo + dm * dm * 8.0f;     // n_a n_b / (n_a + n_b) = 8
+                }
             }
         }
         __syncthreads();
@@ -350,46 +377,34 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                 const int tk = (j >= N ? j - N : j);
                 s += P[ct * BM + sc * N + tk];
             }
-            s = wave_sum(s);
-            if (lane == 0) stat[st] = s * inv_cnt;
-        }
-        __syncthreads();
-        // pass 2: variance about the mean
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int tl = (wm * TM + tm) * 32 + l31;
-            const bool ok = scn[tm] < scenes_here;
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const int g = (wn * TN + tn) >> 1;
-                const float mu = ok ? stat[scn[tm] * G + g] : 0.f;
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float d = acc[tm][tn][r] - mu; s += d * d; }
-                s += __shfl_xor(s, 32, 64);
-                if (half == 0) P[(wn * TN + tn) * BM + tl] = s;
-            }
-        }
-        __syncthreads();
-        for (int st = wave; st < nstat; st += NW) {
-            const int sc = st / G, g = st % G;
-            float s = 0.f;
+            const float mu = wave_sum(s) * inv_cnt;
+            float q = 0.f;
             for (int j = lane; j < 2 * N; j += 64) {
                 const int ct = 2 * g + (j >= N ? 1 : 0);
                 const int tk = (j >= N ? j - N : j);
-                s += P[ct * BM + sc * N + tk];
+                const float d = P[ct * BM + sc * N + tk] * (1.0f / 32.0f) - mu;
+                q += Q[ct * BM + sc * N + tk] + 32.0f * d * d;
             }
-            s = wave_sum(s);
-            if (lane == 0) stat[spt * G + st] = 1.0f / sqrtf(s * inv_cnt + p.eps);
+            q = wave_sum(q);
+            if (lane == 0) {
+                stat[st] = mu;
+                stat[spt * G + st] = 1.0f / sqrtf(q * inv_cnt + p.eps);
+            }
+        }
+        if (ss_lds) {
+#pragma unroll
+            for (int j = 0; j < SSL_MAX * 2 * BN / T; ++j) {
+                const int f = tid + T * j;
+                if (f / (2 * BN) < scenes_here) ssl[f] = ssv[j];
+            }
         }
         __syncthreads();
         // Per-row tables so that the store loop below has no integer division and no conditioning-mode branches:
-        // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index.
-        // Blocks are scene-aligned, so the first scene of the block is rb * spt.
+        // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index
+        // (LDS-staged rows: the scene's slot in ssl; otherwise the row of the global table).
         float* rowst = smem;                                        // [G][BM][2]
         int* rowss = reinterpret_cast<int*>(stat + 192);            // [BM]; stat holds at most 2 * 40 * 2 floats
         {
-            const int64_t scene0 = (int64_t)rb * spt;
             for (int t = tid; t < BM; t += T) {
                 const int sc = t / N;
                 const bool ok = t < rows_here;
@@ -399,8 +414,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                     rowst[(g * BM + t) * 2 + 1] = ok ? stat[spt * G + sc * G + g] : 0.f;
                 }
                 int ssr = 0;
-                if (p.scale_shift && ok) {
-                    if (p.ss_mode == DSC_SS_PER_SCENE) ssr = (int)(scene0 + sc);
+                if (has_ss && ok) {
+                    if (ss_lds) ssr = sc;
+                    else if (p.ss_mode == DSC_SS_PER_SCENE) ssr = (int)(scene0 + sc);
                     else if (p.ss_mode == DSC_SS_PER_SLOT) ssr = t - sc * N;
                     else if (p.ss_mode == DSC_SS_BY_INDEX) ssr = (int)p.ss_index[scene0 + sc];
                     else ssr = (int)(row0 + t);
@@ -412,7 +428,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         DSC_STAMP(3);
         float* zp = p.preact ? p.preact + (int64_t)z * p.sy : nullptr;
         const bool yfast = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-        const bool has_ss = p.scale_shift != nullptr;
         // normalise, affine, scale/shift, SiLU, residual, store -- in the transposed (row-major) patch layout
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -445,7 +460,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                         if (zq) *reinterpret_cast<f32x4*>(zq) = v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) * rs * ga[e] + be[e];
-                        if (has_ss) {
+                        if (ss_lds) {
+                            const float* ss = ssl + rowss[tl] * (2 * BN) + (wn * TN + tn) * 32 + cq * 4;
+                            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
+                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + BN);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] * (sc4[e] + 1.0f) + sh4[e];
+                        } else if (has_ss) {
                             const float* ss = ssb + (int64_t)rowss[tl] * p.ld_ss;
                             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
                             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + p.n);
