@@ -135,7 +135,6 @@ def test_train_on_batch_plan_equals_autograd_training(tmp_path, monkeypatch):
     s = _sample("uncond", 8, 12, nc)
     x = torch.cat([s["translations"], s["sizes"], s["angles"], s["class_labels"], s["objfeats_32"]], -1)
     t = torch.tensor([5, 100, 300, 500, 700, 900, 950, 999], device=dev())
-    cond = ma._instance_condition(8, dev())
 
     def fresh_forward(model):
         net = Unet1D(**dict(W.UNCOND_BEDROOM))
@@ -157,7 +156,7 @@ def test_train_on_batch_plan_equals_autograd_training(tmp_path, monkeypatch):
         worst = max(_relnorm(p, q) for p, q in zip(ma.parameters(), mb.parameters()))
         assert worst < 1e-5, worst
         with torch.no_grad():                         # engine path with derived weights cached across optimizer steps
-            out = ma.diffusion.model(x, t, cond, None)
+            out = ma.diffusion.model(x, t, ma._instance_condition(8, dev()), None)
         assert _relnorm(out, fresh_forward(ma)) < 1e-6, "stale derived weights after FusedAdam steps"
         torch.manual_seed(5)
         va = validate_on_batch(ma, s, tcfg)
