@@ -47,6 +47,17 @@ class WsItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class TnGroup(C.Structure):
+    _fields_ = [("a1", C.c_void_p), ("lda1", C.c_int64), ("k1", C.c_int32),
+                ("a2", C.c_void_p), ("lda2", C.c_int64), ("k2", C.c_int32),
+                ("dy", C.c_void_p), ("ldd", C.c_int64),
+                ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("dbias", C.c_void_p),
+                ("m", C.c_int32), ("n", C.c_int32), ("kvalid", C.c_int32),
+                ("tile0", C.c_int32),
+                ("ws_offset", C.c_int64)]
+
+
 class WsBwdItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dw_std", C.c_void_p), ("dw", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
@@ -75,6 +86,8 @@ SIGNATURES = {
     "dsc_gemm_tn_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p,
                                   C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_gemm_tn_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "dsc_gemm_tn_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_int64,
+                                          C.c_void_p]),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
                                       c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,

@@ -173,6 +173,61 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
 #endif
     DSC_STAGGER();
     DSC_STAMP(0);
+    // GroupNorm epilogue inputs that do not depend on the product are requested BEFORE the main loop: (scale, shift) of a
+    // time-conditioned block is one row per scene, staged in LDS after the statistics instead of being gathered row by row
+    // between the output stores (the compiler cannot hoist those gathers over the stores -- possible aliasing -- which
+    // serialised one L2 round trip per 8 output rows); issued here, the loads are long complete when the epilogue starts
+    // and do not queue behind the residual prefetch (s_waitcnt vmcnt retires loads in order).
+    constexpr int SSV = GN ? (SSL_MAX * 2 * BN / T) : 1;
+    const int spt = GN ? BM / N : 1;
+    const int scenes_here = GN ? rows_here / N : 0;
+    const int64_t scene0 = (int64_t)rb * spt;                 // blocks are scene-aligned
+    const bool has_ss = GN && p.scale_shift != nullptr;
+    const bool ss_lds = has_ss && (p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX) && scenes_here <= SSL_MAX;
+    float ssv[SSV];
+    if constexpr (GN) {
+        if (ss_lds) {
+#pragma unroll
+            for (int j = 0; j < SSV; ++j) {
+                const int f = tid + T * j;                     // (scene, half, column) flattened
+                const int sc = f / (2 * BN), hc = f % (2 * BN);
+                ssv[j] = 0.f;
+                if (sc < scenes_here) {
+                    const int64_t row = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + sc : p.ss_index[scene0 + sc];
+                    ssv[j] = p.scale_shift[row * p.ld_ss + (hc >= BN ? p.n : 0) + col0 + (hc % BN)];
+                }
+            }
+        }
+    }
+    // Outputs leave through LDS (see the epilogue); the flags are needed before the main loop because the residual prefetch
+    // is issued inside its last iterations.
+    const bool rfast = res && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0);
+    const bool fast = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (col0 + BN <= p.n) &&
+                      (!res || rfast);
+    const int tr = lane >> 3, cq = lane & 7;
+    // EPF: every residual quad this lane will add in the epilogue is requested while the LAST TWO K tiles are still being
+    // multiplied, so the whole HBM burst of the residual stream (42 MB per layer at M = 20480) lands under MFMA work and
+    // the GroupNorm statistics instead of in front of the output stores.  16*TM*TN extra VGPRs, live from there on.
+    f32x4 rpre[EPF ? TM * TN * 4 : 1];
+    const bool use_pre = EPF && rfast && (GN || fast);
+    auto prefetch_residual = [&]() {
+        if constexpr (EPF) {
+            if (use_pre) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
+                            const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
+                            const int tlc = tl < rows_here ? tl : 0;
+                            rpre[(tn * TM + tm) * 4 + i] = *reinterpret_cast<const f32x4*>(res + (row0 + tlc) * p.ldr + c);
+                        }
+            }
+        }
+    };
+    bool prefetched = false;
     load_tile(0);
     if constexpr (PIPE) {
         static_assert(DB, "PIPE needs the double-buffered LDS stages");
@@ -255,13 +310,35 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             __syncthreads();
         }
     } else {
-        for (int kt = 0; kt < nk; ++kt) {
+        // the last two K tiles are peeled (straight-line waits, see below).  GroupNorm kernels only: the plain tiles carry
+        // wider staging registers (BK = 64) and would spill with the residual quads live across the main loop
+        const int npeel = (EPF && GN && nk >= 3) ? 2 : 0;
+        for (int kt = 0; kt < nk - npeel; ++kt) {
             store_tile(smem);
             __syncthreads();
             if (kt == 0) DSC_STAMP(1);
             if (kt + 1 < nk) load_tile(kt + 1);
             compute_tile(smem);
             __syncthreads();
+        }
+        if constexpr (EPF && GN) {
+            if (npeel) {
+                // K tile nk-2: its operands are already in flight; request tile nk-1, THEN the residual quads -- the wait
+                // for tile nk-1 at the next staging step only covers loads older than the residual burst
+                store_tile(smem);
+                __syncthreads();
+                load_tile(nk - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch_residual();
+                prefetched = true;
+                __builtin_amdgcn_sched_barrier(0);
+                compute_tile(smem);
+                __syncthreads();
+                store_tile(smem);
+                __syncthreads();
+                compute_tile(smem);
+                __syncthreads();
+            }
         }
     }
 
@@ -286,35 +363,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     // Outputs leave through LDS: the MFMA layout (lane = token, 16 scattered channels) would issue 64 scattered 16-byte
     // accesses per instruction; each wave transposes its 32x32 tile in a private LDS patch and then touches HBM as
     // 8 token rows x 128 contiguous bytes per instruction (stores, residual, scale/shift, pre-norm copy all coalesced).
-    const bool rfast = res && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0);
-    const bool fast = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (col0 + BN <= p.n) &&
-                      (!res || rfast);
     constexpr int TLD = 36;
     constexpr int SCR = GN ? 2 * (BN / 32) * BM + 512 + SSL_MAX * 2 * BN : (BN / 32) * BM + 512;   // scratch below the patches
     static_assert(SCR + NW * 32 * TLD <= SMEM, "epilogue scratch must fit in the LDS allocation");
     float* patch = smem + SCR + wave * (32 * TLD);
-    const int tr = lane >> 3, cq = lane & 7;
-
-    // EPF: every residual quad this lane will add is requested NOW, ahead of the GroupNorm statistics, so the HBM latency
-    // of the residual stream hides behind the stats phase instead of being paid tile by tile (the staging / fragment
-    // registers of the main loop are dead here, so the 16*TM*TN extra VGPRs stay inside the main loop's allocation).
-    f32x4 rpre[EPF ? TM * TN * 4 : 1];
-    const bool use_pre = EPF && rfast && (GN || fast);
-    if constexpr (EPF) {
-        if (use_pre) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
-                        const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
-                        const int tlc = tl < rows_here ? tl : 0;
-                        rpre[(tn * TM + tm) * 4 + i] = *reinterpret_cast<const f32x4*>(res + (row0 + tlc) * p.ldr + c);
-                    }
-        }
-    }
+    if (!prefetched) prefetch_residual();          // short K or a pipelined main loop: request the residual here
 
     if constexpr (GN) {
         constexpr int G = BN / 64;        // GroupNorm groups covered by this block
@@ -323,28 +376,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         float* Q = smem + CT * BM;        // [CT][BM] per-token sums of squares about the token's own mean
         float* stat = smem + 2 * CT * BM; // [spt*G] mean, then [spt*G] rstd  (spt * G <= 80 for N >= 4)
         float* ssl = stat + 512;          // [scenes][2][BN] staged (scale, shift) rows (conditioning shared by a scene)
-        const int spt = BM / N;
-        const int scenes_here = rows_here / N;
         const int nstat = scenes_here * G;
         const float inv_cnt = 1.0f / (64.0f * (float)N);
-        const int64_t scene0 = (int64_t)rb * spt;             // blocks are scene-aligned
-        const bool has_ss = p.scale_shift != nullptr;
-        // (scale, shift) of time-conditioned blocks is one row per scene: stage the block's rows in LDS now (the loads fly
-        // during the statistics) instead of gathering them row by row between the output stores -- the compiler cannot hoist
-        // those gathers over the stores (possible aliasing), which serialised one L2 round trip per 8 output rows
-        const bool ss_lds = has_ss && (p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX) && scenes_here <= SSL_MAX;
-        float ssv[SSL_MAX * 2 * BN / T > 0 ? SSL_MAX * 2 * BN / T : 1];
-        if (ss_lds) {
-#pragma unroll
-            for (int j = 0; j < SSL_MAX * 2 * BN / T; ++j) {
-                const int f = tid + T * j;                     // (scene, half, column) flattened
-                const int sc = f / (2 * BN), hc = f % (2 * BN);
-                if (sc < scenes_here) {
-                    const int64_t row = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + sc : p.ss_index[scene0 + sc];
-                    ssv[j] = p.scale_shift[row * p.ld_ss + (hc >= BN ? p.n : 0) + col0 + (hc % BN)];
-                }
-            }
-        }
         // One pass over the accumulators (Chan's pairwise update): every lane reduces its 16 channels to (sum, centred sum
         // of squares), the two lane halves are merged, then one wave per (scene, group) merges the 2N token entries about
         // their common mean.  No E[x^2] - E[x]^2 cancellation anywhere: same quality as mean-then-variance, half the passes.
@@ -393,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         }
         if (ss_lds) {
 #pragma unroll
-            for (int j = 0; j < SSL_MAX * 2 * BN / T; ++j) {
+            for (int j = 0; j < SSV; ++j) {
                 const int f = tid + T * j;
                 if (f / (2 * BN) < scenes_here) ssl[f] = ssv[j];
             }

@@ -34,15 +34,11 @@ struct TnArgs {
     int ktiles;                               // number of 128-wide k tiles
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
-    __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
+__device__ __forceinline__ void tn_block(const TnArgs& p, const int it, const int jt, const int split, float* As, float* Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
-    const int it = blockIdx.x % p.ktiles, jt = blockIdx.x / p.ktiles;
     const int i0 = it * 128, j0 = jt * 128;
-    const int split = blockIdx.y;
     const long m_begin = (long)split * p.chunk;
     const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
 
@@ -136,6 +132,88 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
                         if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[a][b][4 * q + e];
                 }
             }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
+    tn_block(p, blockIdx.x % p.ktiles, blockIdx.x / p.ktiles, blockIdx.y, As, Bs);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Grouped TN GEMM: the weight gradients of MANY layers in one launch.  Weight gradients are leaves of the backward pass, and
+// the static training plan keeps every activation alive, so they can all be deferred: with ~2200 output tiles in flight
+// the token dimension needs (almost) no splitting -- the per-layer launch above has to cut M = 20480 into 32 slabs to fill
+// 256 CUs with the 16 tiles of one 512 x 512 gradient, and then writes + re-reads 32 partial copies of every gradient.
+// Tiles of one group are consecutive ids, remapped so that they land on the same XCD: they walk the tokens in step and share
+// the A / dY rows through that XCD's L2.
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_find_group(const dsc_tn_group* __restrict__ g, int count, int tile) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (g[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int count,
+                                                                 const int splits, float* __restrict__ workspace) {
+    __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
+    int tile = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) tile = (tile & 7) * (nb >> 3) + (tile >> 3);     // XCD x works on the contiguous chunk of tiles
+    const int gi = tn_find_group(groups, count, tile);
+    const dsc_tn_group g = groups[gi];
+    const int K = g.k1 + g.k2;
+    const int ktiles = (K + 127) / 128;
+    const int local = tile - g.tile0;
+    const int split = blockIdx.y;
+    TnArgs p;
+    p.a1 = g.a1; p.lda1 = g.lda1; p.k1 = g.k1; p.a2 = g.a2; p.lda2 = g.lda2; p.k2 = g.k2; p.dy = g.dy; p.ldd = g.ldd;
+    p.m = g.m; p.n = g.n; p.kvalid = g.kvalid; p.ktiles = ktiles;
+    p.chunk = ((g.m + splits - 1) / splits + 31) / 32 * 32;
+    if (splits == 1) {
+        p.out = g.out; p.ldo = g.ldo; p.bias_out = g.dbias; p.slab = 0; p.bias_slab = 0;
+    } else {
+        const long wslab = (long)g.n * g.kvalid;
+        p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
+        p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
+    }
+    tn_block(p, local % ktiles, local / ktiles, split, As, Bs);
+}
+
+// second stage of the grouped launch when splits > 1: every block sums the slabs of its own 128 x 128 tile (fixed order)
+__global__ __launch_bounds__(256) void reduce_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int count,
+                                                             const int splits, const float* __restrict__ workspace) {
+    const int tile = blockIdx.x;
+    const int gi = tn_find_group(groups, count, tile);
+    const dsc_tn_group g = groups[gi];
+    const int K = g.k1 + g.k2;
+    const int ktiles = (K + 127) / 128;
+    const int local = tile - g.tile0;
+    const int it = local % ktiles, jt = local / ktiles;
+    const long wslab = (long)g.n * g.kvalid;
+    const float* ws = workspace + g.ws_offset;
+    const int i_lo = it * 128, i_hi = (i_lo + 128 < g.kvalid) ? i_lo + 128 : g.kvalid;
+    const int j_lo = jt * 128, j_hi = (j_lo + 128 < g.n) ? j_lo + 128 : g.n;
+    const int w = i_hi - i_lo;
+    if (w > 0) {
+        for (int e = threadIdx.x; e < (j_hi - j_lo) * w; e += 256) {
+            const int j = j_lo + e / w, i = i_lo + e % w;
+            float acc = 0.f;
+            for (int s = 0; s < splits; ++s) acc += ws[(long)s * wslab + (long)j * g.kvalid + i];
+            g.out[(long)j * g.ldo + i] = acc;
+        }
+    }
+    if (g.dbias && it == 0) {
+        for (int j = j_lo + threadIdx.x; j < j_hi; j += 256) {
+            float acc = 0.f;
+            for (int s = 0; s < splits; ++s) acc += ws[wslab * splits + (long)s * g.n + j];
+            g.dbias[j] = acc;
+        }
     }
 }
 
@@ -1067,6 +1145,25 @@ extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const 
                                dbias, (long)n);
             DSC_LAUNCH_CHECK();
         }
+    }
+    return 0;
+}
+
+extern "C" int dsc_gemm_tn_grouped_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, int32_t splits,
+                                       float* workspace, int64_t workspace_floats, int64_t workspace_needed,
+                                       dsc_stream_t stream) {
+    if (!groups_dev || count < 1 || total_tiles < count || splits < 1 || splits > 64) return DSC_EINVAL;
+    if (splits > 1 && (!workspace || workspace_floats < workspace_needed || workspace_needed < 1)) return DSC_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3((unsigned)total_tiles, (unsigned)splits), dim3(256), 0, s, groups_dev, count,
+                       splits, workspace);
+    DSC_LAUNCH_CHECK();
+    if (splits > 1) {
+        DSC_CLEAR_STALE_ERROR();
+        hipLaunchKernelGGL(reduce_grouped_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, groups_dev, count, splits,
+                           workspace);
+        DSC_LAUNCH_CHECK();
     }
     return 0;
 }

@@ -174,6 +174,54 @@ class HipBackend:
         return self._with_scratch(wsf, lambda wp, wn: (fn, (ap, lda, k1, a2p, lda2, k2, dp, ldd, op, ldo, dbp, m, n, kv,
                                                             wp if wsf else None, wn if wsf else 0), "dsc_gemm_tn_f32"))
 
+    def gemm_tn_grouped(self, items):
+        """items: dicts(a, dy, out, a2, kvalid, dbias) -> ONE launch (plus the slab reduction when the tokens are split)."""
+        import numpy as np
+        arr = (self.lib.TnGroup * len(items))()
+        tile0, ws_off = 0, 0
+        per_group = []
+        for i, it in enumerate(items):
+            a, dy, out, a2, dbias = it["a"], it["dy"], it["out"], it.get("a2"), it.get("dbias")
+            ap, lda = self._mat(a)
+            dp, ldd = self._mat(dy)
+            op, ldo = self._mat(out)
+            k1 = a.shape[1]
+            a2p, lda2, k2 = (None, 0, 0)
+            if a2 is not None:
+                a2p, lda2 = self._mat(a2)
+                k2 = a2.shape[1]
+            m, n = dy.shape
+            kv = (k1 + k2) if it.get("kvalid") is None else it["kvalid"]
+            # the checks dsc_gemm_tn_f32 makes on the host (the grouped entry point only sees a device table)
+            if (k1 & 3) or (k2 & 3) or (n & 3) or (k2 > 0 and k1 % 128) or not (1 <= kv <= k1 + k2):
+                raise RuntimeError("gemm_tn_grouped: bad shape m=%d n=%d k1=%d k2=%d kvalid=%d" % (m, n, k1, k2, kv))
+            if (ap % 16) or (lda & 3) or (dp % 16) or (ldd & 3) or (k2 and ((a2p % 16) or (lda2 & 3))):
+                raise RuntimeError("gemm_tn_grouped: operands must be 16-byte aligned with row strides multiple of 4")
+            if a.shape[0] != m or (a2 is not None and a2.shape[0] != m) or tuple(out.shape) != (n, kv):
+                raise RuntimeError("gemm_tn_grouped: shape mismatch")
+            g = arr[i]
+            g.a1, g.lda1, g.k1, g.a2, g.lda2, g.k2 = ap, lda, k1, a2p, lda2, k2
+            g.dy, g.ldd, g.out, g.ldo = dp, ldd, op, ldo
+            g.dbias = dbias.data_ptr() if dbias is not None else None
+            g.m, g.n, g.kvalid, g.tile0 = m, n, kv, tile0
+            tile0 += ((n + 127) // 128) * ((k1 + k2 + 127) // 128)
+            per_group.append((n, kv, ldo))
+        total = tile0
+        # enough tiles for ~8 rounds of 2 blocks per CU; long layers then run (almost) unsplit
+        splits = max(1, min(32, -(-8 * 512 // total)))
+        if splits > 1:
+            for i, (n, kv, ldo) in enumerate(per_group):
+                if ldo != kv:
+                    raise RuntimeError("gemm_tn_grouped: split outputs must be dense [n][kvalid]")
+                arr[i].ws_offset = ws_off
+                ws_off += (n * kv + n) * splits
+        table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+        self.keep.append((table, items))
+        fn = self.lib.fn("dsc_gemm_tn_grouped_f32")
+        tp, cnt = table.data_ptr(), len(items)
+        return self._with_scratch(ws_off, lambda wp, wn: (fn, (tp, cnt, total, splits, wp if splits > 1 else None,
+                                                                wn if splits > 1 else 0, ws_off), "dsc_gemm_tn_grouped_f32"))
+
     def colsum(self, x, out):
         xp, ldx = self._mat(x)
         m, n = x.shape
@@ -289,6 +337,7 @@ class TrainPlan:
         self._transposes = []
         self._cur = self.fwd
         self.bwd_writes = []              # (index of the LAST step of a backward op, (G offset, length)) per finished gradient
+        self._tn_pending = []             # deferred weight-gradient GEMMs (leaves of the backward): one grouped launch
         self.n_adds = 0
         C_in = net.channels
         dev = self.device
@@ -357,6 +406,18 @@ class TrainPlan:
     # Invariant that makes aliasing safe: a gradient tensor is only ever handed to handles whose backward emitters run
     # strictly LATER (they belong to earlier forward ops), and every emitter finishes reading its own dy before it hands dy
     # on.  So accumulating in place into an aliased buffer can never disturb a reader.
+    # Deferred weight-gradient GEMMs (self.tn) read their dy LATER, so a gradient buffer that a pending one reads must not be
+    # accumulated into before that launch: _guard flushes the pending group first.
+    def _guard(self, t):
+        """Call before modifying gradient tensor ``t`` in place."""
+        if not self._tn_pending:
+            return
+        key = t.untyped_storage().data_ptr()
+        for it in self._tn_pending:
+            if it["dy"].untyped_storage().data_ptr() == key:
+                self.flush_tn()
+                return
+
     def g_alias(self, h, src):
         """grad(h) += src where src is a finished gradient tensor: no copy when it is the first contribution."""
         if not h.ng:
@@ -364,6 +425,7 @@ class TrainPlan:
         if h.g is None:
             h.g = src
         else:
+            self._guard(h.g)
             self.emit(self.be.add(h.g, src))
             self.n_adds += 1
 
@@ -372,6 +434,7 @@ class TrainPlan:
         if h.g is None:
             h.g = self.new(*h.t.shape)
             return h.g, False
+        self._guard(h.g)
         return h.g, True
 
     def g_write(self, h, produce):
@@ -384,6 +447,7 @@ class TrainPlan:
         else:
             tmp = self.new(*h.t.shape)
             produce(tmp)
+            self._guard(h.g)
             self.emit(self.be.add(h.g, tmp))
             self.n_adds += 1
 
@@ -409,6 +473,7 @@ class TrainPlan:
             self._gemm_acc(dy, wt, buf, False)
         elif same_parent:
             buf = torch.as_strided(a.g, (a.g.shape[0], K), (K, 1))
+            self._guard(buf)
             self._gemm_acc(dy, wt, buf, True)
         else:
             tmp = self.new(dy.shape[0], K)
@@ -428,6 +493,22 @@ class TrainPlan:
                 self.emit(self.be.gemm(dy[:, c0:c1], wt[:, c0:c1], dst, residual=dst if (acc or c0 > 0) else None))
         else:
             self.emit(self.be.gemm(dy, wt, dst, residual=dst if acc else None))
+
+    def tn(self, a, dy, out, a2=None, kvalid=None, dbias=None, params=(), after=None):
+        """Weight gradient out = dy^T [a | a2]: deferred -- it is a leaf of the backward pass and its operands stay alive, so
+        all of them run as one grouped launch (flush_tn) instead of one M-split launch + slab reduction per layer."""
+        self._tn_pending.append({"a": a, "dy": dy, "out": out, "a2": a2, "kvalid": kvalid, "dbias": dbias,
+                                 "params": tuple(p for p in params if p is not None), "after": after})
+
+    def flush_tn(self):
+        items, self._tn_pending = self._tn_pending, []
+        if not items:
+            return
+        self.emit(self.be.gemm_tn_grouped(items))
+        for it in items:
+            if it["after"] is not None:
+                it["after"]()
+        self.wrote(*[p for it in items for p in it["params"]])
 
     def wT(self, w2d, npad=None):
         """Transposed copy [K, n(pad)] of a weight, refreshed once per step at the start of the backward pass."""
@@ -471,14 +552,15 @@ class TrainPlan:
             if npad != n:
                 tw = self.new(npad, K)
                 tb = self.new(1, npad) if bias is not None else None
-                self.emit(self.be.gemm_tn(a.t, dyp, tw, a2.t if a2 is not None else None,
-                                          dbias=tb.view(-1) if tb is not None else None))
-                self.emit(self.be.copy(gw, tw[:n]))
-                if bias is not None:
-                    self.emit(self.be.copy(gb.view(1, n), tb[:, :n]))
+
+                def unpad():
+                    self.emit(self.be.copy(gw, tw[:n]))
+                    if bias is not None:
+                        self.emit(self.be.copy(gb.view(1, n), tb[:, :n]))
+                self.tn(a.t, dyp, tw, a2.t if a2 is not None else None, dbias=tb.view(-1) if tb is not None else None,
+                        params=(weight, bias), after=unpad)
             else:
-                self.emit(self.be.gemm_tn(a.t, dyp, gw, a2.t if a2 is not None else None, dbias=gb))
-            self.wrote(weight, bias)
+                self.tn(a.t, dyp, gw, a2.t if a2 is not None else None, dbias=gb, params=(weight, bias))
             if residual is not None:
                 self.g_alias(residual, dy)
         self._tape.append(bw)
@@ -497,8 +579,7 @@ class TrainPlan:
         def bw():
             if y.g is None:
                 return
-            self.emit(self.be.gemm_tn(xpad, y.g, self.gview(weight), kvalid=k, dbias=self.flat.grad_view(bias)))
-            self.wrote(weight, bias)
+            self.tn(xpad, y.g, self.gview(weight), kvalid=k, dbias=self.flat.grad_view(bias), params=(weight, bias))
         self._tape.append(bw)
         return y
 
@@ -554,7 +635,7 @@ class TrainPlan:
                 self.emit(self.be.colsum(slot_tmp.view(scenes, self.N * 2 * D), red.view(-1)))
                 self.emit(self.be.copy(dss, red))
             self.g_gemm(a, a2, dz, self.ws_t[id(conv)])
-            self.emit(self.be.gemm_tn(a.t, dz, self.dws[id(conv)], a2.t if a2 is not None else None))
+            self.tn(a.t, dz, self.dws[id(conv)], a2.t if a2 is not None else None)
             self._ws_pending.append(conv)
             if residual is not None:
                 self.g_alias(residual, dy)
@@ -705,9 +786,8 @@ class TrainPlan:
             self.g_gemm(t2, None, dss_t, tw_t)
             if self.per_block_grads:
                 return                       # the per-block TN launches were emitted next to each block (bucket overlap)
-            self.emit(be.gemm_tn(t2.t, dss_t, tgw, dbias=tgb))
-            self.wrote_range(*fl.pack_range["t_w"])
-            self.wrote_range(*fl.pack_range["t_b"])
+            self.tn(t2.t, dss_t, tgw, dbias=tgb, after=lambda: (self.wrote_range(*fl.pack_range["t_w"]),
+                                                                 self.wrote_range(*fl.pack_range["t_b"])))
         self._tape.append(bw_time_pack)
         self._t_pack = (t2, dss_t, tgw, tgb)
 
@@ -724,9 +804,8 @@ class TrainPlan:
 
             def bw_ctx_pack():
                 self.g_gemm(cact, None, dss_c, cw_t)
-                self.emit(be.gemm_tn(cact.t, dss_c, cgw, dbias=cgb))
-                self.wrote_range(*fl.pack_range["c_w"])
-                self.wrote_range(*fl.pack_range["c_b"])
+                self.tn(cact.t, dss_c, cgw, dbias=cgb, after=lambda: (self.wrote_range(*fl.pack_range["c_w"]),
+                                                                      self.wrote_range(*fl.pack_range["c_b"])))
             self._tape.append(bw_ctx_pack)
 
         def t_ss(rb):
@@ -741,8 +820,17 @@ class TrainPlan:
             sl = slice(i * 2 * D, (i + 1) * 2 * D)
             return ss_c.t[:, sl], self.ctx_mode, dss_c[:, sl]
 
+        # data parallel: weight gradients are flushed (grouped TN launch + weight-standardisation backward) every few blocks so
+        # that finished buckets of G can leave while the backward continues; a single GPU flushes once, at the end
+        self._post_count = 0
+
+        def post_flush():
+            self._post_count += 1
+            if self._post_count % 7 == 0:
+                self._flush_ws_pending()
+
         def cblock(rb, a):
-            return self.resblock(rb, a, None, c_ss(rb), post=self._flush_ws_pending if self.per_block_grads else None)
+            return self.resblock(rb, a, None, c_ss(rb), post=post_flush if self.per_block_grads else None)
 
         def tb_(rb, a, a2=None):
             post = None
@@ -751,14 +839,15 @@ class TrainPlan:
                 sl = slice(i * 2 * D, (i + 1) * 2 * D)
 
                 def post(i=i, sl=sl):
-                    # data parallel: this block's rows of the packed time-MLP gradient right after the block's backward, so
-                    # that the bucket holding them can be all-reduced while the rest of the backward runs
-                    self._flush_ws_pending()
-                    self.emit(be.gemm_tn(t2.t, dss_t[:, sl], tgw[sl], dbias=tgb[sl]))
-                    o, _ = fl.pack_range["t_w"]
-                    self.wrote_range(o + i * 2 * D * tw.shape[1], 2 * D * tw.shape[1])
-                    ob, _ = fl.pack_range["t_b"]
-                    self.wrote_range(ob + i * 2 * D, 2 * D)
+                    # data parallel: this block's rows of the packed time-MLP gradient join the pending group right after the
+                    # block's backward, so that the bucket holding them can be all-reduced while the rest of the backward runs
+                    def done(i=i):
+                        o, _ = fl.pack_range["t_w"]
+                        self.wrote_range(o + i * 2 * D * tw.shape[1], 2 * D * tw.shape[1])
+                        ob, _ = fl.pack_range["t_b"]
+                        self.wrote_range(ob + i * 2 * D, 2 * D)
+                    self.tn(t2.t, dss_t[:, sl], tgw[sl], dbias=tgb[sl], after=done)
+                    post_flush()
             return self.resblock(rb, a, a2, t_ss(rb), post=post)
 
         # ---- input embedding
@@ -872,6 +961,7 @@ class TrainPlan:
         self.d_cross = self.cross_in.g if self.cross_in is not None else None
 
     def _flush_ws_pending(self):
+        self.flush_tn()                               # the d w_std operands of the weight-standardisation backward
         convs = self._ws_pending[self._ws_flushed:]
         if not convs:
             return

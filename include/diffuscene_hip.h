@@ -172,6 +172,27 @@ int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const float* a2, 
                     int32_t m, int32_t n, int32_t kvalid, float* workspace, int64_t workspace_floats, dsc_stream_t stream);
 int64_t dsc_gemm_tn_workspace_floats(int32_t m, int32_t n, int32_t k);
 
+/* The same for MANY layers in one launch (static training plan: weight gradients are leaves of the backward pass and every
+ * activation stays alive, so they are deferred and computed together -- enough output tiles to fill the chip without cutting
+ * the token dimension into 32 slabs per layer).  `groups_dev` is a DEVICE array of `count` descriptors (pointers are device
+ * pointers; the constraints of dsc_gemm_tn_f32 apply to each and are validated by the caller that builds the table);
+ * tile0 = number of 128 x 128 output tiles of all earlier groups (ceil(n/128) * ceil((k1+k2)/128) each), total_tiles their
+ * sum.  splits == 1 writes `out` / `dbias` directly; splits > 1 cuts every group's tokens into `splits` ranges whose partial
+ * results go to workspace + ws_offset ([splits][n*kvalid] then [splits][n], per group) and are summed in a fixed order by
+ * a second launch.  workspace_needed = end of the last group's area. */
+typedef struct dsc_tn_group {
+    const float* a1; int64_t lda1; int32_t k1;
+    const float* a2; int64_t lda2; int32_t k2;
+    const float* dy; int64_t ldd;
+    float* out; int64_t ldo;
+    float* dbias;
+    int32_t m, n, kvalid;
+    int32_t tile0;
+    int64_t ws_offset;
+} dsc_tn_group;
+int dsc_gemm_tn_grouped_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, int32_t splits,
+                            float* workspace, int64_t workspace_floats, int64_t workspace_needed, dsc_stream_t stream);
+
 /* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */
 int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,
                    int64_t workspace_floats, dsc_stream_t stream);

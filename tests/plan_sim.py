@@ -246,6 +246,15 @@ class SimBackend:
                 dbias.copy_(dy.double().sum(dim=0).float())
         return self._step("gemm_tn", f)
 
+    def gemm_tn_grouped(self, items):
+        steps = [self.gemm_tn(it["a"], it["dy"], it["out"], it.get("a2"), it.get("kvalid"), it.get("dbias")) for it in items]
+        self.counts["gemm_tn_grouped"] = self.counts.get("gemm_tn_grouped", 0) + 1
+
+        def f():
+            for st in steps:
+                st()
+        return f
+
     def colsum(self, x, out):
         def f():
             out.copy_(x.double().sum(dim=0).float())

@@ -393,3 +393,32 @@ def test_fused_adam_matches_torch_adam_with_clipping():
     cpu.param_groups[0]["params"][0].grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         cpu.step()
+
+
+@pytest.mark.parametrize("scale", [1, 40])
+def test_grouped_weight_gradient_gemm(scale):
+    """dsc_gemm_tn_grouped_f32: many weight gradients in one launch (mixed shapes: two K segments, zero-padded small K with
+    kvalid, bias column sums, tiny token counts) vs fp64; `scale` makes the group large enough for the unsplit path."""
+    from diffuscene_amd.train_plan import HipBackend
+    be = HipBackend(dev())
+    M = 1280
+    shapes = [(M, 512, 512, 0, None, True), (M, 512, 512, 512, None, False), (M, 512, 32, 0, 25, True),
+              (64, 1024, 512, 0, None, True), (M, 384, 512, 0, None, False), (M, 32, 512, 0, None, True)] * scale
+    items, refs = [], []
+    for i, (m, n, k1, k2, kv, bias) in enumerate(shapes):
+        a, dy = rnd(m, k1, seed=100 + i).to(dev()), rnd(m, n, seed=200 + i).to(dev())
+        a2 = rnd(m, k2, seed=300 + i).to(dev()) if k2 else None
+        K = k1 + k2
+        out = torch.full((n, kv or K), float("nan"), device=dev())
+        db = torch.full((n,), float("nan"), device=dev()) if bias else None
+        items.append(dict(a=a, dy=dy, out=out, a2=a2, kvalid=kv, dbias=db))
+        A = torch.cat([a, a2], 1) if k2 else a
+        refs.append(((dy.double().T @ A.double())[:, :kv or K], dy.double().sum(0)))
+    step = be.gemm_tn_grouped(items)
+    be.finalize()
+    be.run([step], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for it, (rw, rb) in zip(items, refs):
+        assert rel(it["out"], rw) < 5e-6
+        if it["dbias"] is not None:
+            assert rel(it["dbias"], rb) < 5e-6
