@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 // the static training plan keeps every activation alive, so they can all be deferred: with ~2200 output tiles in flight
 // the token dimension needs (almost) no splitting -- the per-layer launch above has to cut M = 20480 into 32 slabs to fill
 // 256 CUs with the 16 tiles of one 512 x 512 gradient, and then writes + re-reads 32 partial copies of every gradient.
-// Tiles of one group are consecutive ids, remapped so that they land on the same XCD: they walk the tokens in step and share
-// the A / dY rows through that XCD's L2.
+// Tiles of one group are consecutive ids: they run concurrently, walk the tokens in step and share the A / dY rows through
+// L2 / Infinity Cache.  The caller orders the groups longest first so that the short ones fill the tail.
 // -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tn_find_group(const dsc_tn_group* __restrict__ g, int count, int tile) {
     int lo = 0, hi = count - 1;
@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const dsc_tn_gr
                                                                  const int splits, float* __restrict__ workspace) {
     __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
     __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
-    int tile = blockIdx.x;
-    const int nb = gridDim.x;
-    if ((nb & 7) == 0) tile = (tile & 7) * (nb >> 3) + (tile >> 3);     // XCD x works on the contiguous chunk of tiles
+    // no XCD remap: groups differ wildly in length (20480 tokens vs 256), so contiguous chunks per XCD would leave some XCDs
+    // idle; round-robin dispatch spreads every group over all XCDs (tiles t and t+8 of a 512 x 512 gradient share their A rows
+    // in one L2, the rest of the sharing happens in the Infinity Cache)
+    const int tile = blockIdx.x;
     const int gi = tn_find_group(groups, count, tile);
     const dsc_tn_group g = groups[gi];
     const int K = g.k1 + g.k2;

@@ -177,9 +177,12 @@ class HipBackend:
     def gemm_tn_grouped(self, items):
         """items: dicts(a, dy, out, a2, kvalid, dbias) -> ONE launch (plus the slab reduction when the tokens are split)."""
         import numpy as np
+        # longest groups first (the block scheduler hands out tiles in id order): the short ones fill the tail
+        items = sorted(items, key=lambda it: -it["dy"].shape[0])
         arr = (self.lib.TnGroup * len(items))()
         tile0, ws_off = 0, 0
         per_group = []
+        long_tiles, m_max = 0, max(it["dy"].shape[0] for it in items)
         for i, it in enumerate(items):
             a, dy, out, a2, dbias = it["a"], it["dy"], it["out"], it.get("a2"), it.get("dbias")
             ap, lda = self._mat(a)
@@ -204,11 +207,15 @@ class HipBackend:
             g.dy, g.ldd, g.out, g.ldo = dp, ldd, op, ldo
             g.dbias = dbias.data_ptr() if dbias is not None else None
             g.m, g.n, g.kvalid, g.tile0 = m, n, kv, tile0
-            tile0 += ((n + 127) // 128) * ((k1 + k2 + 127) // 128)
+            nt = ((n + 127) // 128) * ((k1 + k2 + 127) // 128)
+            tile0 += nt
+            if 2 * m >= m_max:
+                long_tiles += nt
             per_group.append((n, kv, ldo))
         total = tile0
-        # enough tiles for ~8 rounds of 2 blocks per CU; long layers then run (almost) unsplit
-        splits = max(1, min(32, -(-8 * 512 // total)))
+        # the long tiles set the duration: cut the tokens until they make ~8 rounds of 2 blocks per CU (tail < 1/8); with all
+        # layers of a step in one group that is 2 slabs per gradient instead of the 32 of a per-layer launch
+        splits = max(1, min(32, -(-8 * 512 // max(long_tiles, 1))))
         if splits > 1:
             for i, (n, kv, ldo) in enumerate(per_group):
                 if ldo != kv:

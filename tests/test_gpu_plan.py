@@ -167,10 +167,11 @@ def test_train_on_batch_plan_equals_autograd_training(tmp_path, monkeypatch):
         assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb))
 
 
-def test_ddp_reducer_on_rccl_world1_is_bit_identical(tmp_path, monkeypatch):
+def test_ddp_reducer_on_rccl_world1_matches_single_process(tmp_path, monkeypatch):
     """The data-parallel path on the real backend: torch.distributed 'nccl' (= RCCL) with world_size 1 and the reducer forced
     on.  Buckets must be launched from the backward's progress callback, and gradients / updated parameters must equal the
-    single-process graph path bit for bit (sum over one rank, 1/world = 1)."""
+    single-process graph path (sum over one rank, 1/world = 1) up to the summation order of the weight-gradient GEMMs,
+    which the data-parallel plan flushes in several groups instead of one."""
     import torch.distributed as dist
     from diffuscene_amd.networks import optimizer_factory
     from diffuscene_amd.networks.diffusion_scene_layout_ddpm import train_on_batch
@@ -195,8 +196,8 @@ def test_ddp_reducer_on_rccl_world1_is_bit_identical(tmp_path, monkeypatch):
         red = ent["reducer"]
         assert red is not None and len(red.buckets) >= 8
         assert red.launched_during_backward >= 5
-        assert torch.equal(ma._dsc_flat.G, mb._dsc_flat.G)
-        assert torch.equal(ma._dsc_flat.P, mb._dsc_flat.P)
+        assert _relnorm(ma._dsc_flat.G, mb._dsc_flat.G) < 2e-6
+        assert _relnorm(ma._dsc_flat.P, mb._dsc_flat.P) < 2e-6
     finally:
         dist.destroy_process_group()
 
