@@ -201,7 +201,20 @@ __global__ __launch_bounds__(256) void reduce_grouped_kernel(const dsc_tn_group*
     const int i_lo = it * 128, i_hi = (i_lo + 128 < g.kvalid) ? i_lo + 128 : g.kvalid;
     const int j_lo = jt * 128, j_hi = (j_lo + 128 < g.n) ? j_lo + 128 : g.n;
     const int w = i_hi - i_lo;
-    if (w > 0) {
+    const bool vec = (w & 3) == 0 && (g.kvalid & 3) == 0 && (g.ldo & 3) == 0 && (g.ws_offset & 3) == 0 && (wslab & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(g.out) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+    if (w > 0 && vec) {
+        // 32 lanes x 16 bytes cover a 128-wide row; 8 rows per pass
+        const int c4 = (threadIdx.x & 31) * 4, r8 = threadIdx.x >> 5;
+        if (c4 < w) {
+            for (int j = j_lo + r8; j < j_hi; j += 8) {
+                const float* src = ws + (long)j * g.kvalid + i_lo + c4;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+                for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(src + (long)s * wslab);
+                *reinterpret_cast<f32x4*>(g.out + (long)j * g.ldo + i_lo + c4) = acc;
+            }
+        }
+    } else if (w > 0) {
         for (int e = threadIdx.x; e < (j_hi - j_lo) * w; e += 256) {
             const int j = j_lo + e / w, i = i_lo + e % w;
             float acc = 0.f;

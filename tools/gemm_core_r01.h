@@ -1,4 +1,5 @@
 #pragma once
+// ROUND-1 snapshot of diffuscene_amd/csrc/gemm_core.h (git a07da01) under its own namespace: the A/B reference of tools/gemm_tune.py.
 // fp32 MFMA GEMM with fused epilogues for the Unet1D denoiser (gfx950).
 //
 // Every 1x1 conv / linear of the reference denoiser (denoise_net.py) is  Y[m][n] = X[m][k] . W[n][k]^T:
@@ -19,8 +20,9 @@
 // Register-staged prefetch of tile kt+1 overlaps the MFMAs of tile kt; two blocks per CU cover barriers.
 
 #include <type_traits>
-#include "dsc_common.h"
+#include "../diffuscene_amd/csrc/dsc_common.h"
 
+#ifndef DSC_STAMP
 #ifdef DSC_GEMM_TIMING          // tools/gemm_tune.hip only: per-block phase timestamps (shader clock), start stagger
 extern __device__ long long g_dsc_timing[];
 extern __device__ int g_dsc_stagger;      // cycles by which the second resident block of every CU starts late
@@ -31,8 +33,9 @@ extern __device__ int g_dsc_stagger;      // cycles by which the second resident
 #define DSC_STAMP(i) do {} while (0)
 #define DSC_STAGGER() do {} while (0)
 #endif
+#endif
 
-namespace dsc_gemm {
+namespace dsc_gemm_r01 {
 
 // TM x TN : 32x32 MFMA tiles per wave;  WM x WN : waves per block (4 or 8);  BK : K elements per staged tile;
 // DB : double-buffered LDS (one barrier per K tile);  MINW : min waves per SIMD for __launch_bounds__;
@@ -55,14 +58,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     constexpr int STAGE = (BM + BN) * LDT;
     constexpr bool XFULL = (XTOT % T) == 0, WFULL = (WTOT % T) == 0;
 
-    // epilogue scratch: GroupNorm partials (sum + centred sum of squares) | stats + row tables | per-wave transpose patches
-    constexpr int SSL_MAX = 8;
-    constexpr int EPI = (GN ? 2 * (BN / 32) * BM + 512 : (BN / 32) * BM + 512) + NW * 32 * 36;
+    constexpr int EPI = (BN / 32) * BM + 512 + NW * 32 * 36;      // epilogue scratch: GroupNorm partials + per-wave patches
     constexpr int SMEM = ((DB ? 2 : 1) * STAGE > EPI) ? (DB ? 2 : 1) * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    // (scale, shift) rows of the block's scenes: written once at kernel start, read by the store loop -- its own array because
-    // the staging buffers of the main loop occupy smem in between
-    __shared__ __attribute__((aligned(16))) float ssl[GN ? SSL_MAX * 2 * BN : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -175,58 +173,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
 #endif
     DSC_STAGGER();
     DSC_STAMP(0);
-    // GroupNorm epilogue inputs that do not depend on the product are fetched BEFORE the main loop: (scale, shift) of a
-    // time-conditioned block is one row per scene; the block's rows go to LDS here (their latency overlaps the first operand
-    // tile's) instead of being gathered row by row between the output stores -- the compiler cannot hoist those gathers over
-    // the stores (possible aliasing), which serialised one L2 round trip per 8 output rows -- and nothing in the epilogue has
-    // to wait behind the residual prefetch for them (s_waitcnt vmcnt retires loads in order).
-    constexpr int SSV = GN ? (SSL_MAX * 2 * BN / T) : 1;
-    const int spt = GN ? BM / N : 1;
-    const int scenes_here = GN ? rows_here / N : 0;
-    const int64_t scene0 = (int64_t)rb * spt;                 // blocks are scene-aligned
-    const bool has_ss = GN && p.scale_shift != nullptr;
-    const bool ss_lds = has_ss && (p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX) && scenes_here <= SSL_MAX;
     load_tile(0);
-    if constexpr (GN) {
-        if (ss_lds) {
-#pragma unroll
-            for (int j = 0; j < SSV; ++j) {
-                const int f = tid + T * j;                     // (scene, half, column) flattened
-                const int sc = f / (2 * BN), hc = f % (2 * BN);
-                if (sc < scenes_here) {
-                    const int64_t row = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + sc : p.ss_index[scene0 + sc];
-                    ssl[f] = p.scale_shift[row * p.ld_ss + (hc >= BN ? p.n : 0) + col0 + (hc % BN)];
-                }
-            }
-        }
-    }
-    // Outputs leave through LDS (see the epilogue); the flags are needed before the main loop because the residual prefetch
-    // is issued inside its last iterations.
-    const bool rfast = res && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0);
-    const bool fast = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (col0 + BN <= p.n) &&
-                      (!res || rfast);
-    const int tr = lane >> 3, cq = lane & 7;
-    // EPF: every residual quad this lane will add is requested at the top of the epilogue, ahead of the GroupNorm statistics,
-    // so the HBM burst of the residual stream (42 MB per layer at M = 20480) is not paid tile by tile between the stores.
-    f32x4 rpre[EPF ? TM * TN * 4 : 1];
-    const bool use_pre = EPF && rfast && (GN || fast);
-    auto prefetch_residual = [&]() {
-        if constexpr (EPF) {
-            if (use_pre) {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
-                            const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
-                            const int tlc = tl < rows_here ? tl : 0;
-                            rpre[(tn * TM + tm) * 4 + i] = *reinterpret_cast<const f32x4*>(res + (row0 + tlc) * p.ldr + c);
-                        }
-            }
-        }
-    };
     if constexpr (PIPE) {
         static_assert(DB, "PIPE needs the double-buffered LDS stages");
         constexpr int S = BK / 8;                 // 8-wide K steps per staged tile
@@ -339,43 +286,62 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     // Outputs leave through LDS: the MFMA layout (lane = token, 16 scattered channels) would issue 64 scattered 16-byte
     // accesses per instruction; each wave transposes its 32x32 tile in a private LDS patch and then touches HBM as
     // 8 token rows x 128 contiguous bytes per instruction (stores, residual, scale/shift, pre-norm copy all coalesced).
+    const bool rfast = res && ((p.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(res) & 15) == 0);
+    const bool fast = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && (col0 + BN <= p.n) &&
+                      (!res || rfast);
     constexpr int TLD = 36;
-    constexpr int SCR = GN ? 2 * (BN / 32) * BM + 512 : (BN / 32) * BM + 512;   // scratch below the patches
+    constexpr int SCR = (BN / 32) * BM + 512;                // GroupNorm scratch (P + stats, N >= 4) lives below the patches
     static_assert(SCR + NW * 32 * TLD <= SMEM, "epilogue scratch must fit in the LDS allocation");
     float* patch = smem + SCR + wave * (32 * TLD);
-    // the residual burst is requested here, at the top of the epilogue, and lands under the statistics.  (Measured: requesting it
-    // under the last one or two K tiles slows the main loop by what it saves -- the burst competes with the operand loads.)
-    prefetch_residual();
+    const int tr = lane >> 3, cq = lane & 7;
+
+    // EPF: every residual quad this lane will add is requested NOW, ahead of the GroupNorm statistics, so the HBM latency
+    // of the residual stream hides behind the stats phase instead of being paid tile by tile (the staging / fragment
+    // registers of the main loop are dead here, so the 16*TM*TN extra VGPRs stay inside the main loop's allocation).
+    f32x4 rpre[EPF ? TM * TN * 4 : 1];
+    const bool use_pre = EPF && rfast && (GN || fast);
+    if constexpr (EPF) {
+        if (use_pre) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int tl = (wm * TM + tm) * 32 + tr + 8 * i;
+                        const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
+                        const int tlc = tl < rows_here ? tl : 0;
+                        rpre[(tn * TM + tm) * 4 + i] = *reinterpret_cast<const f32x4*>(res + (row0 + tlc) * p.ldr + c);
+                    }
+        }
+    }
 
     if constexpr (GN) {
         constexpr int G = BN / 64;        // GroupNorm groups covered by this block
         constexpr int CT = BN / 32;       // 32-channel tiles in the block
-        float* P = smem;                  // [CT][BM] per-token sums over the 32 channels of a tile
-        float* Q = smem + CT * BM;        // [CT][BM] per-token sums of squares about the token's own mean
-        float* stat = smem + 2 * CT * BM; // [spt*G] mean, then [spt*G] rstd  (spt * G <= 80 for N >= 4)
+        float* P = smem;                  // [CT][BM] per-token partial sums
+        float* stat = smem + CT * BM;     // [spt*G] mean, then [spt*G] rstd
+        const int spt = BM / N;
+        const int scenes_here = rows_here / N;
         const int nstat = scenes_here * G;
         const float inv_cnt = 1.0f / (64.0f * (float)N);
-        // One pass over the accumulators (Chan's pairwise update): every lane reduces its 16 channels to (sum, centred sum
-        // of squares), the two lane halves are merged, then one wave per (scene, group) merges the 2N token entries about
-        // their common mean.  No E[x^2] - E[x]^2 cancellation anywhere: same quality as mean-then-variance, half the passes.
+        int scn[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int tl = (wm * TM + tm) * 32 + l31;
+            scn[tm] = tl / N;
+        }
+        // pass 1: mean
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int tl = (wm * TM + tm) * 32 + l31;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                float s16 = 0.f;
+                float s = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s16 += acc[tm][tn][r];
-                const float m16 = s16 * (1.0f / 16.0f);
-                float q16 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float d = acc[tm][tn][r] - m16; q16 += d * d; }
-                const float so = __shfl_xor(s16, 32, 64), qo = __shfl_xor(q16, 32, 64);
-                const float dm = (so - s16) * (1.0f / 16.0f);
-                if (half == 0) {
-                    P[(wn * TN + tn) * BM + tl] = s16 + so;
-                    Q[(wn * TN + tn) * BM + tl] = q16 + qo + dm * dm * 8.0f;     // n_a n_b / (n_a + n_b) = 8
-                }
+                for (int r = 0; r < 16; ++r) s += acc[tm][tn][r];
+                s += __shfl_xor(s, 32, 64);
+                if (half == 0) P[(wn * TN + tn) * BM + tl] = s;
             }
         }
         __syncthreads();
@@ -387,27 +353,46 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                 const int tk = (j >= N ? j - N : j);
                 s += P[ct * BM + sc * N + tk];
             }
-            const float mu = wave_sum(s) * inv_cnt;
-            float q = 0.f;
-            for (int j = lane; j < 2 * N; j += 64) {
-                const int ct = 2 * g + (j >= N ? 1 : 0);
-                const int tk = (j >= N ? j - N : j);
-                const float d = P[ct * BM + sc * N + tk] * (1.0f / 32.0f) - mu;
-                q += Q[ct * BM + sc * N + tk] + 32.0f * d * d;
-            }
-            q = wave_sum(q);
-            if (lane == 0) {
-                stat[st] = mu;
-                stat[spt * G + st] = 1.0f / sqrtf(q * inv_cnt + p.eps);
+            s = wave_sum(s);
+            if (lane == 0) stat[st] = s * inv_cnt;
+        }
+        __syncthreads();
+        // pass 2: variance about the mean
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int tl = (wm * TM + tm) * 32 + l31;
+            const bool ok = scn[tm] < scenes_here;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int g = (wn * TN + tn) >> 1;
+                const float mu = ok ? stat[scn[tm] * G + g] : 0.f;
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float d = acc[tm][tn][r] - mu; s += d * d; }
+                s += __shfl_xor(s, 32, 64);
+                if (half == 0) P[(wn * TN + tn) * BM + tl] = s;
             }
         }
         __syncthreads();
+        for (int st = wave; st < nstat; st += NW) {
+            const int sc = st / G, g = st % G;
+            float s = 0.f;
+            for (int j = lane; j < 2 * N; j += 64) {
+                const int ct = 2 * g + (j >= N ? 1 : 0);
+                const int tk = (j >= N ? j - N : j);
+                s += P[ct * BM + sc * N + tk];
+            }
+            s = wave_sum(s);
+            if (lane == 0) stat[spt * G + st] = 1.0f / sqrtf(s * inv_cnt + p.eps);
+        }
+        __syncthreads();
         // Per-row tables so that the store loop below has no integer division and no conditioning-mode branches:
-        // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index
-        // (LDS-staged rows: the scene's slot in ssl; otherwise the row of the global table).
+        // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index.
+        // Blocks are scene-aligned, so the first scene of the block is rb * spt.
         float* rowst = smem;                                        // [G][BM][2]
         int* rowss = reinterpret_cast<int*>(stat + 192);            // [BM]; stat holds at most 2 * 40 * 2 floats
         {
+            const int64_t scene0 = (int64_t)rb * spt;
             for (int t = tid; t < BM; t += T) {
                 const int sc = t / N;
                 const bool ok = t < rows_here;
@@ -417,9 +402,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                     rowst[(g * BM + t) * 2 + 1] = ok ? stat[spt * G + sc * G + g] : 0.f;
                 }
                 int ssr = 0;
-                if (has_ss && ok) {
-                    if (ss_lds) ssr = sc;
-                    else if (p.ss_mode == DSC_SS_PER_SCENE) ssr = (int)(scene0 + sc);
+                if (p.scale_shift && ok) {
+                    if (p.ss_mode == DSC_SS_PER_SCENE) ssr = (int)(scene0 + sc);
                     else if (p.ss_mode == DSC_SS_PER_SLOT) ssr = t - sc * N;
                     else if (p.ss_mode == DSC_SS_BY_INDEX) ssr = (int)p.ss_index[scene0 + sc];
                     else ssr = (int)(row0 + t);
@@ -431,6 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         DSC_STAMP(3);
         float* zp = p.preact ? p.preact + (int64_t)z * p.sy : nullptr;
         const bool yfast = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+        const bool has_ss = p.scale_shift != nullptr;
         // normalise, affine, scale/shift, SiLU, residual, store -- in the transposed (row-major) patch layout
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -463,13 +448,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                         if (zq) *reinterpret_cast<f32x4*>(zq) = v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) * rs * ga[e] + be[e];
-                        if (ss_lds) {
-                            const float* ss = ssl + rowss[tl] * (2 * BN) + (wn * TN + tn) * 32 + cq * 4;
-                            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
-                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + BN);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] * (sc4[e] + 1.0f) + sh4[e];
-                        } else if (has_ss) {
+                        if (has_ss) {
                             const float* ss = ssb + (int64_t)rowss[tl] * p.ld_ss;
                             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
                             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + p.n);
@@ -576,4 +555,4 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     DSC_STAMP(4);
 }
 
-}  // namespace dsc_gemm
+}  // namespace dsc_gemm_r01

@@ -2,6 +2,7 @@
 // (diffuscene_amd/csrc/gemm_core.h) so tools/gemm_tune.py can time them on a real MI355X.
 #define DSC_GEMM_TIMING 1
 #include "../diffuscene_amd/csrc/gemm_core.h"
+#include "gemm_core_r01.h"
 
 __device__ long long g_dsc_timing[4096 * 8];
 __device__ int g_dsc_stagger = 0;
@@ -19,6 +20,16 @@ static int run(const dsc_gemm_args* a, hipStream_t s, int stagger) {
     const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
     const int nrb = (a->m + rpb - 1) / rpb, ncb = (a->n + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE, EPF>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
+    return (int)hipGetLastError();
+}
+
+template <int TM, int TN, int WM, int WN, bool GN, int BK>
+static int run_r01(const dsc_gemm_args* a, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
+    const int nrb = (a->m + rpb - 1) / rpb, ncb = (a->n + BN - 1) / BN;
+    hipLaunchKernelGGL((dsc_gemm_r01::gemm_kernel<TM, TN, WM, WN, GN, BK, false, 2, true, false, true>), dim3(nrb * ncb, a->batch),
+                       dim3(64 * WM * WN), 0, s, *a, ncb);
     return (int)hipGetLastError();
 }
 
@@ -61,6 +72,8 @@ extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* s
         V(22, 1, 2, 2, 2, 32, false, 4, true)
         VE(23, 5, 1, 1, 4, 32, 2)
         VE(24, 5, 1, 1, 8, 64, 2)
+        case 25: return gn ? run_r01<5, 1, 1, 4, true, 32>(a, s) : run_r01<5, 1, 1, 4, false, 32>(a, s);
+        case 26: return gn ? -1 : run_r01<5, 1, 1, 8, false, 64>(a, s);
     }
     return -1;
 }
@@ -76,8 +89,9 @@ extern "C" const char* tune_name(int variant) {
         "13: PIPE 160x128 4w BK16 (2 blk/CU)", "14: PIPE 160x256 8w BK32 (1 blk/CU)", "15: PIPE 160x256 8w BK16",
         "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD",
         "18: 64x64 4w (many small blocks)", "19: 128x128 4w 3 waves/SIMD", "20: 128x64 4w", "21: 96x128 4w", "22: 64x128 4w",
-        "23: product 160x128 4w + epilogue residual prefetch", "24: product 160x256 8w BK64 + epilogue residual prefetch"};
-    return (variant >= 0 && variant < 25) ? names[variant] : nullptr;
+        "23: product 160x128 4w + epilogue residual prefetch", "24: product 160x256 8w BK64 + epilogue residual prefetch",
+        "25: ROUND-1 product 160x128 4w (git a07da01)", "26: ROUND-1 product 160x256 8w BK64 (git a07da01)"};
+    return (variant >= 0 && variant < 27) ? names[variant] : nullptr;
 }
 
 // ---- scene-resident layer kernel (diffuscene_amd/csrc/scene_core.h): one block of 512 threads per scene -------------

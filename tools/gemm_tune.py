@@ -37,7 +37,7 @@ def main():
     if stag:
         lib.tune_set_stagger(stag)
         print("stagger: second resident block starts %d cycles late" % stag)
-    NV = 25
+    NV = 27
     B, N = 256, 80
     M = B * N
     torch.manual_seed(0)
@@ -56,7 +56,7 @@ def main():
                 y = torch.zeros(M, 512, device=dev)
                 if gn and 18 <= v <= 22:
                     continue                     # small tiles cannot hold an 80-token scene
-                if gn and v in (7, 24):
+                if gn and v in (7, 24, 26):
                     continue                     # 8-wave BK64 tile is a plain-GEMM tile
                 rr = None if nores else r
                 if gn:
@@ -91,7 +91,7 @@ def main():
     import numpy as np
     lib.tune_read_timing.argtypes = [C.c_void_p, C.c_int]
     for gn in (0, 1):
-        for v in ((1, 23) if only is not None else (1, 13, 14)):
+        for v in ((25, 23) if only is not None else (1, 13, 14)):
             a = torch.randn(M, 512, device=dev); w = torch.randn(512, 512, device=dev) * 0.05
             y = torch.zeros(M, 512, device=dev)
             rr = None if nores else r
