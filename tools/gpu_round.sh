@@ -1,0 +1,29 @@
+#!/bin/bash
+# One gpurun call: GPU tests, smoke, benches, rocprofv3 kernel traces (each step under its own timeout).
+# Usage (repo root on the GPU box):  bash tools/gpu_round.sh <tag> [steps...]   steps default: tests smoke bench trace
+set -u
+TAG=${1:-r02}; shift || true
+STEPS=${*:-tests smoke bench trace}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+for s in $STEPS; do
+case $s in
+tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/${TAG}_tests.log 2>&1; tail -3 $O/${TAG}_tests.log ;;
+smoke) timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -1 $O/${TAG}_smoke.log ;;
+bench) timeout 600 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -1 $O/${TAG}_bench_default.json | cut -c1-600 ;;
+benchall) for c in bedroom21 text complete arrange; do timeout 400 python bench.py --config $c > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err; tail -1 $O/${TAG}_bench_$c.json | cut -c1-300; done ;;
+trace) cd /tmp && export TMPDIR=/tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_sample -o s -- python $R/bench.py --mode sample --steps 20 --warmup 3 --no-cpu-baseline --no-full-loop > $O/${TAG}_trace_sample.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_train -o t -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_trace_train.log 2>&1
+  cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_trace_sample -name "*.db" | head -1) > $O/${TAG}_sample_kernel_trace.txt 2>&1; python tools/rocpd_summary.py $(find $O/${TAG}_trace_train -name "*.db" | head -1) > $O/${TAG}_train_kernel_trace.txt 2>&1; head -12 $O/${TAG}_sample_kernel_trace.txt; head -25 $O/${TAG}_train_kernel_trace.txt ;;
+pmc) cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/${TAG}_pmc_sample -o p -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_sample.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o f -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_fetch.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o w -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_write.log 2>&1
+  cd $R ;;
+*) echo "unknown step $s" ;;
+esac
+done
+ls $O | grep $TAG | head -40
