@@ -209,6 +209,11 @@ def git_head():
         return subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL,
                                        text=True).strip()
     except Exception:
+        pass
+    try:                                   # the GPU box gets a snapshot without .git: tools/gpu_round.sh leaves the head here
+        with open(os.path.join(ROOT, "GIT_HEAD")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 
@@ -222,10 +227,11 @@ def roofline_dominant_kernel(plan, N, config_name):
     structs = [a[0]._obj for a in steps]          # ctypes.byref(struct) keeps the struct in ._obj
     sel = [(a, s) for a, s in zip(steps, structs) if s.k1 + s.k2 == 512]
     s = ops.stream_ptr()
-    for a, _ in sel[:4]:
-        fn(*a, s)
+    for _ in range(3):                     # the clocks take milliseconds to ramp after an idle sync: warm up, then time
+        for a, _ in sel:
+            fn(*a, s)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 3
+    reps = 5
     ev0.record()
     for _ in range(reps):
         for a, _ in sel:

@@ -40,7 +40,7 @@ namespace dsc_gemm {
 // PIPE (needs DB): MFMA fragments are software-pipelined one 8-wide K step ahead in registers, across the single
 // barrier per K tile, so one wave per SIMD can keep the matrix pipe busy on its own.
 template <int TM, int TN, int WM, int WN, bool GN, int BK = 32, bool DB = false, int MINW = 2, bool XCD = false,
-          bool PIPE = false, bool EPF = false>
+          bool PIPE = false, bool EPF = false, int PROBE = 0, bool IL = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm_args p, const int ncolblk) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     // epilogue scratch: GroupNorm partials (sum + centred sum of squares) | stats + row tables | per-wave transpose patches
     constexpr int SSL_MAX = 8;
     constexpr int EPI = (GN ? 2 * (BN / 32) * BM + 512 : (BN / 32) * BM + 512) + NW * 32 * 36;
-    constexpr int SMEM = ((DB ? 2 : 1) * STAGE > EPI) ? (DB ? 2 : 1) * STAGE : EPI;
+    constexpr int IL_STAGE = (BM + BN) * BK;  // IL: unpadded rows, XOR-swizzled 16-byte slots, two stages
+    constexpr int MAINF = IL ? 2 * IL_STAGE : (DB ? 2 : 1) * STAGE;
+    constexpr int SMEM = (MAINF > EPI) ? MAINF : EPI;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
     // (scale, shift) rows of the block's scenes: written once at kernel start, read by the store loop -- its own array because
     // the staging buffers of the main loop occupy smem in between
@@ -112,18 +114,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
 #pragma unroll
         for (int i = 0; i < XF; ++i) {
             // branch-free: out-of-range rows read row 0 of the tile (always valid); they are zeroed when staged, so the
-            // wait for the load sits at the ds_write one tile later, not here
-            const int f = tid + T * i;
+            // wait for the load sits at the ds_write one tile later, not here.  IL: threads past the end of a ragged last
+            // round wrap to the start of the tile (a duplicate of what another thread stages -- same address, same data)
+            int f = tid + T * i;
+            if (IL && !XFULL && f >= XTOT) f -= XTOT;
             const int r = f / KQ, kq = f % KQ;
-            const bool ok = (XFULL || f < XTOT) && r < rows_here;
+            const bool ok = (IL || XFULL || f < XTOT) && r < rows_here;
             xr[i] = *reinterpret_cast<const f32x4*>(ab + (row0 + (ok ? r : 0)) * lda + kk + kq * 4);
         }
 #pragma unroll
         for (int i = 0; i < WF; ++i) {
-            const int f = tid + T * i;
+            int f = tid + T * i;
+            if (IL && !WFULL && f >= WTOT) f -= WTOT;
             const int r = f / KQ, kq = f % KQ;
             const int c = col0 + r;
-            const bool ok = (WFULL || f < WTOT) && c < p.n;
+            const bool ok = (IL || WFULL || f < WTOT) && c < p.n;
             wr[i] = *reinterpret_cast<const f32x4*>(w + (int64_t)(ok ? c : col0) * p.ldw + k0 + kq * 4);
         }
     };
@@ -168,10 +173,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     };
 
 #ifdef DSC_GEMM_TIMING
-    if (threadIdx.x == 0) {
-        g_dsc_timing[(blockIdx.x & 4095) * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
-        g_dsc_timing[(blockIdx.x & 4095) * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-    }
 #endif
     DSC_STAGGER();
     DSC_STAMP(0);
@@ -227,7 +228,144 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             }
         }
     };
-    if constexpr (PIPE) {
+    if constexpr (IL) {
+        // Interleaved main loop.  One K tile = S groups of TM*TN*4 MFMAs; everything else a K tile needs -- the next group's
+        // fragment reads, the LDS writes of tile kt+1 (register-staged one tile ahead), the global loads of tile kt+2 -- is
+        // slotted BETWEEN the MFMAs of this wave's own instruction stream (sched_group_barrier), because the two waves of a SIMD
+        // belong to the same block and run in lock-step: a stretch of non-MFMA instructions leaves the matrix pipe idle
+        // (measured: 12 k of 178 k main-loop cycles at K = 512 for the grouped order).  LDS rows are unpadded (BK floats); the
+        // 16-byte slot of k-quad q in row r sits at q ^ ((r >> 1) & 7): fragment reads (16 consecutive rows, one quad) and
+        // staging writes (2 rows x 8 quads) both touch 16 distinct slots -> conflict-free without padding.
+        static_assert(BK == 32, "IL: BK = 32 (8 quads per row)");
+        constexpr int S = BK / 8;
+        constexpr int MM = TM * TN * 4;           // MFMAs per group
+        constexpr int NLD = XF + WF;              // staging instructions (global loads / LDS writes) per thread and tile
+        static_assert(MM >= TM + TN + NLD, "IL: the MFMA groups are too short to carry the staging instructions");
+        const int swz = (l31 >> 1) & 7;
+        int foff[S];                              // float offset of this lane's fragment quad for each 8-wide K step
+#pragma unroll
+        for (int k8 = 0; k8 < S; ++k8) foff[k8] = (((k8 * 2 + half) ^ swz) << 2);
+        f32x4 xfA[TM], wfA[TN], xfB[TM], wfB[TN];
+        auto frags = [&](const float* stage, int k8, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
+            const float* Xs = stage;
+            const float* Ws = stage + BM * BK;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                xf[tm] = *reinterpret_cast<const f32x4*>(Xs + ((wm * TM + tm) * 32 + l31) * BK + foff[k8]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                wf[tn] = *reinterpret_cast<const f32x4*>(Ws + ((wn * TN + tn) * 32 + l31) * BK + foff[k8]);
+        };
+        auto mma = [&](const f32x4 (&xf)[TM], const f32x4 (&wf)[TN]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tn][j], xf[tm][j], acc[tm][tn], 0, 0, 0);
+        };
+        // rows / columns past the edge were loaded from a valid row and are NOT zeroed: they only feed accumulators of
+        // rows / columns that are never stored (nor enter the GroupNorm statistics)
+        auto stage_tile = [&](float* stage) {
+            float* Xs = stage;
+            float* Ws = stage + BM * BK;
+#pragma unroll
+            for (int i = 0; i < XF; ++i) {
+                int f = tid + T * i;
+                if (!XFULL && f >= XTOT) f -= XTOT;          // duplicate slot, identical data (see load_tile): no branch
+                const int r = f / KQ, kq = f % KQ;
+                *reinterpret_cast<f32x4*>(Xs + r * BK + ((kq ^ ((r >> 1) & 7)) << 2)) = xr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < WF; ++i) {
+                int f = tid + T * i;
+                if (!WFULL && f >= WTOT) f -= WTOT;
+                const int r = f / KQ, kq = f % KQ;
+                *reinterpret_cast<f32x4*>(Ws + r * BK + ((kq ^ ((r >> 1) & 7)) << 2)) = wr[i];
+            }
+        };
+        stage_tile(smem);
+        load_tile(nk > 1 ? 1 : 0);
+        __syncthreads();
+        DSC_STAMP(1);
+        frags(smem, 0, xfA, wfA);
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* cur = smem + (kt & 1) * IL_STAGE;
+            float* nxt = smem + ((kt + 1) & 1) * IL_STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            // group 0: MFMAs(A) with the fragment reads of group 1
+            frags(cur, 1, xfB, wfB);
+            mma(xfA, wfA);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM - 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 1: MFMAs(B) with the fragment reads of group 2 and the LDS writes of tile kt+1
+            frags(cur, 2, xfA, wfA);
+            stage_tile(nxt);
+            mma(xfB, wfB);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM - (TM + TN) - NLD, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 2: MFMAs(A) with the fragment reads of group 3 and the global loads of tile kt+2
+            frags(cur, 3, xfB, wfB);
+            load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
+            mma(xfA, wfA);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM - (TM + TN) - NLD, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 3: MFMAs(B); the block barrier (tile kt+1 complete in LDS, tile kt's reads retired) and the first
+            // fragment reads of tile kt+1 sit in the middle of the group
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfB[tn][j], xfB[tm][j], acc[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            frags(nxt, 0, xfA, wfA);
+#pragma unroll
+            for (int j = 2; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfB[tn][j], xfB[tm][j], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM / 2 - (TM + TN), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    } else if constexpr (PIPE) {
         static_assert(DB, "PIPE needs the double-buffered LDS stages");
         constexpr int S = BK / 8;                 // 8-wide K steps per staged tile
         static_assert(S == 2 || S == 4, "BK must be 16 or 32");
@@ -307,6 +445,34 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             if (kt + 1 < nk) store_tile(smem + ((kt + 1) & 1) * STAGE);
             __syncthreads();
         }
+    } else if constexpr (PROBE > 0) {
+        // tools/gemm_tune.hip only -- attribution probes of the main loop (results are wrong on purpose):
+        //   1: no global loads / LDS stores after the first tile   2: + fragments read once   3: + no barriers
+        store_tile(smem);
+        __syncthreads();
+        DSC_STAMP(1);
+        f32x4 xf0[TM], wf0[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) xf0[tm] = *reinterpret_cast<const f32x4*>(smem + ((wm * TM + tm) * 32 + l31) * LDT + half * 4);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) wf0[tn] = *reinterpret_cast<const f32x4*>(smem + BM * LDT + ((wn * TN + tn) * 32 + l31) * LDT + half * 4);
+        for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (PROBE == 1) {
+                compute_tile(smem);
+            } else {
+#pragma unroll
+                for (int k8 = 0; k8 < BK / 8; ++k8)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf0[tn][j], xf0[tm][j], acc[tm][tn], 0, 0, 0);
+            }
+            if constexpr (PROBE < 3) { __syncthreads(); __syncthreads(); }
+            else __builtin_amdgcn_sched_barrier(0);
+        }
     } else {
         for (int kt = 0; kt < nk; ++kt) {
             store_tile(smem);
@@ -378,7 +544,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                 }
             }
         }
+        DSC_STAMP(5);
         __syncthreads();
+        DSC_STAMP(6);
         for (int st = wave; st < nstat; st += NW) {
             const int sc = st / G, g = st % G;
             float s = 0.f;
@@ -402,6 +570,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             }
         }
         __syncthreads();
+        DSC_STAMP(7);
         // Per-row tables so that the store loop below has no integer division and no conditioning-mode branches:
         // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index
         // (LDS-staged rows: the scene's slot in ssl; otherwise the row of the global table).

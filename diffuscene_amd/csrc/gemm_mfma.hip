@@ -19,7 +19,8 @@ int check_common(const dsc_gemm_args* a) {
     return 0;
 }
 
-template <int TM, int TN, int WM, int WN, bool GN, int BKT = 32>
+// IL: interleaved main loop (gemm_core.h) -- every tile whose MFMA groups are long enough to carry the staging instructions
+template <int TM, int TN, int WM, int WN, bool GN, bool IL = true>
 int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     constexpr int BN = 32 * TN * WN;
     const int nrb = (a->m + rows_per_blk - 1) / rows_per_blk;
@@ -28,7 +29,7 @@ int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     // XCD-aware block order: the column blocks sharing a token tile run on one XCD and hit its L2; EPF: residual
     // quads are requested at the top of the epilogue (measured -3..-6 % per launch with a residual input)
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BKT, false, 2, true, false, true>), grid, dim3(64 * WM * WN), 0, s, *a, ncb);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, false, 2, true, false, true, 0, IL>), grid, dim3(64 * WM * WN), 0, s, *a, ncb);
     DSC_LAUNCH_CHECK();
     return 0;
 }
@@ -46,7 +47,7 @@ extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
     int rc = check_common(a);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool wide = (a->n % 256) == 0 && (a->k1 % 64) == 0 && (a->k2 % 64) == 0;
+    const bool wide = (a->n % 256) == 0;
     struct Cand { int bm, bn, id; };
     const Cand cands[5] = {{160, 256, 0}, {160, 128, 1}, {128, 128, 2}, {96, 128, 3}, {64, 64, 4}};
     int best = -1;
@@ -57,13 +58,13 @@ extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
         if (best < 0 || c < best_cost) { best = cands[i].id; best_cost = c; }
     }
     switch (best) {
-        // 8 waves x (5x1 tiles): 160 x 256 block tile, one block per CU -- fewer LDS-staged bytes per MFMA (measured
-        // +10 % over the 4-wave 160 x 128 tile on M=20480, n=512); needs full 256-column tiles and K tiles of 64
-        case 0: return launch<5, 1, 1, 8, false, 64>(a, 160, s);
+        // 8 waves x (5x1 tiles): 160 x 256 block tile, one block per CU (fewer LDS-staged bytes per MFMA, shortest
+        // epilogue); needs full 256-column tiles
+        case 0: return launch<5, 1, 1, 8, false>(a, 160, s);
         case 1: return launch<5, 1, 1, 4, false>(a, 160, s);
         case 2: return launch<2, 2, 2, 2, false>(a, 128, s);
         case 3: return launch<3, 1, 1, 4, false>(a, 96, s);
-        default: return launch<1, 1, 2, 2, false>(a, 64, s);
+        default: return launch<1, 1, 2, 2, false, false>(a, 64, s);
     }
 }
 
@@ -87,11 +88,12 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scene-aligned tiles: a block holds floor(BM / N) whole scenes; padded rows are wasted MFMA work
     struct Cand { int bm, bn; };
-    const Cand cands[4] = {{160, 128}, {128, 128}, {96, 128}, {64, 64}};
+    const Cand cands[5] = {{160, 256}, {160, 128}, {128, 128}, {96, 128}, {64, 64}};
     int best = -1;
     long best_cost = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (cands[i].bm < N) continue;
+        if (cands[i].bn == 256 && (a->n % 256)) continue;
         const int rpb = (cands[i].bm / N) * N;
         const long c = tile_cost(a->m, rpb, a->n, cands[i].bm, cands[i].bn);
         if (best < 0 || c < best_cost) { best = i; best_cost = c; }
@@ -99,9 +101,10 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
     if (best < 0) return DSC_ERANGE;
     const int rpb = (cands[best].bm / N) * N;
     switch (best) {
-        case 0: return launch<5, 1, 1, 4, true>(a, rpb, s);
-        case 1: return launch<2, 2, 2, 2, true>(a, rpb, s);
-        case 2: return launch<3, 1, 1, 4, true>(a, rpb, s);
-        default: return launch<1, 1, 2, 2, true>(a, rpb, s);
+        case 0: return launch<5, 1, 1, 8, true>(a, rpb, s);
+        case 1: return launch<5, 1, 1, 4, true>(a, rpb, s);
+        case 2: return launch<2, 2, 2, 2, true>(a, rpb, s);
+        case 3: return launch<3, 1, 1, 4, true>(a, rpb, s);
+        default: return launch<1, 1, 2, 2, true, false>(a, rpb, s);
     }
 }

@@ -239,6 +239,11 @@ def add_scalar_i64(t, delta):
     return t
 
 
+def stream_delay(ns):
+    """Idle the current stream for ``ns`` nanoseconds (device-side, capturable)."""
+    _lib.check(_lib.fn("dsc_stream_delay")(int(ns), stream_ptr()), "dsc_stream_delay")
+
+
 def complete_overwrite(x, partial, noise, t, sqrt_ac, sqrt_1mac):
     _c(x, "x"); _c(partial, "partial"); _c(noise, "noise"); _dev(t, "t", torch.int64)
     b, n, c = x.shape

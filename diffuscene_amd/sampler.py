@@ -47,6 +47,11 @@ def _chains_for(B):
     return n if (n > 1 and B % n == 0 and B // n >= 64) else 1
 
 
+def _chain_offset_ns():
+    import os
+    return int(os.environ.get("DSC_CHAIN_OFFSET_NS", "50000"))
+
+
 class _StepGraph:
     def __init__(self, diff, model, shape, device, condition, condition_cross, clip_denoised, replay=False,
                  partial_shape=None):
@@ -60,6 +65,7 @@ class _StepGraph:
                                   None if condition_cross is None else condition_cross[i * Bc:(i + 1) * Bc],
                                   time_table=use_table, slot=i) for i in range(nch)]
         self.plan = self.plans[0]
+        self.chain_offset_ns = _chain_offset_ns()
         self.side = [torch.cuda.Stream(device=device) for _ in range(nch - 1)]
         tb = diff.tables(device)
         ca, cb = diff._coeffs(tb)
@@ -103,6 +109,8 @@ class _StepGraph:
             run_chain(0)
             for i, st in enumerate(self.side):
                 with torch.cuda.stream(st):
+                    if self.chain_offset_ns > 0:
+                        ops.stream_delay(self.chain_offset_ns * (i + 1))
                     run_chain(i + 1)
             for st in self.side:
                 cur.wait_stream(st)

@@ -14,12 +14,12 @@ extern "C" int tune_read_timing(long long* host, int nblocks) {
 
 using dsc_gemm::gemm_kernel;
 
-template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false, bool EPF = false>
+template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false, bool EPF = false, int PROBE = 0, bool IL = false>
 static int run(const dsc_gemm_args* a, hipStream_t s, int stagger) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
     const int nrb = (a->m + rpb - 1) / rpb, ncb = (a->n + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE, EPF>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE, EPF, PROBE, IL>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
     return (int)hipGetLastError();
 }
 
@@ -72,6 +72,14 @@ extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* s
         V(22, 1, 2, 2, 2, 32, false, 4, true)
         VE(23, 5, 1, 1, 4, 32, 2)
         VE(24, 5, 1, 1, 8, 64, 2)
+        case 27: return run<5, 1, 1, 8, false, 64, false, 2, true, false, true, 1>(a, s, stagger);
+        case 28: return run<5, 1, 1, 8, false, 64, false, 2, true, false, true, 2>(a, s, stagger);
+        case 29: return run<5, 1, 1, 8, false, 64, false, 2, true, false, true, 3>(a, s, stagger);
+        case 30: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 1>(a, s, stagger);
+        case 31: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 2>(a, s, stagger);
+        case 32: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 3>(a, s, stagger);
+        case 33: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, true>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, true>(a, s, stagger);
+        case 34: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, true>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, true>(a, s, stagger);
         case 25: return gn ? run_r01<5, 1, 1, 4, true, 32>(a, s) : run_r01<5, 1, 1, 4, false, 32>(a, s);
         case 26: return gn ? -1 : run_r01<5, 1, 1, 8, false, 64>(a, s);
     }
@@ -90,8 +98,11 @@ extern "C" const char* tune_name(int variant) {
         "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD",
         "18: 64x64 4w (many small blocks)", "19: 128x128 4w 3 waves/SIMD", "20: 128x64 4w", "21: 96x128 4w", "22: 64x128 4w",
         "23: product 160x128 4w + epilogue residual prefetch", "24: product 160x256 8w BK64 + epilogue residual prefetch",
-        "25: ROUND-1 product 160x128 4w (git a07da01)", "26: ROUND-1 product 160x256 8w BK64 (git a07da01)"};
-    return (variant >= 0 && variant < 27) ? names[variant] : nullptr;
+        "25: ROUND-1 product 160x128 4w (git a07da01)", "26: ROUND-1 product 160x256 8w BK64 (git a07da01)",
+        "27: PROBE 8w BK64: no global loads / LDS stores", "28: PROBE 8w BK64: + fragments read once", "29: PROBE 8w BK64: + no barriers",
+        "30: PROBE 4w BK32: no global loads / LDS stores", "31: PROBE 4w BK32: + fragments read once", "32: PROBE 4w BK32: + no barriers",
+        "33: IL 160x256 8w BK32 interleaved staging (1 blk/CU)", "34: IL 160x128 4w BK32 interleaved staging (2 blk/CU)"};
+    return (variant >= 0 && variant < 35) ? names[variant] : nullptr;
 }
 
 // ---- scene-resident layer kernel (diffuscene_amd/csrc/scene_core.h): one block of 512 threads per scene -------------
