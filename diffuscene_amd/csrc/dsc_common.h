@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../include/diffuscene_hip.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -40,7 +40,7 @@ namespace dsc_gemm {
 // PIPE (needs DB): MFMA fragments are software-pipelined one 8-wide K step ahead in registers, across the single
 // barrier per K tile, so one wave per SIMD can keep the matrix pipe busy on its own.
 template <int TM, int TN, int WM, int WN, bool GN, int BK = 32, bool DB = false, int MINW = 2, bool XCD = false,
-          bool PIPE = false, bool EPF = false, int PROBE = 0, bool IL = false>
+          bool PIPE = false, bool EPF = false, int PROBE = 0, int IL = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm_args p, const int ncolblk) {
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
@@ -56,16 +56,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     constexpr bool XFULL = (XTOT % T) == 0, WFULL = (WTOT % T) == 0;
 
     // epilogue scratch: GroupNorm partials (sum + centred sum of squares) | stats + row tables | per-wave transpose patches
-    constexpr int SSL_MAX = 8;
+    constexpr int SSL_MAX = (IL && NW == 4 && BM + BN > 256) ? 4 : 8;   // 2 blocks per CU: 2 x (stages + tables) <= 160 KB
     constexpr int EPI = (GN ? 2 * (BN / 32) * BM + 512 : (BN / 32) * BM + 512) + NW * 32 * 36;
     constexpr int IL_STAGE = (BM + BN) * BK;  // IL: unpadded rows, XOR-swizzled 16-byte slots, two stages
     constexpr int MAINF = IL ? 2 * IL_STAGE : (DB ? 2 : 1) * STAGE;
     constexpr int SMEM = (MAINF > EPI) ? MAINF : EPI;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    // (scale, shift) rows of the block's scenes: written once at kernel start, read by the store loop -- its own array because
-    // the staging buffers of the main loop occupy smem in between
-    __shared__ __attribute__((aligned(16))) float ssl[GN ? SSL_MAX * 2 * BN : 4];
-
+    // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA queue before every fragment read):
+    // [ operand stages / epilogue scratch | (scale, shift) rows of the block's scenes | per-row tables of the GN epilogue ]
+    constexpr int SSLF = GN ? SSL_MAX * 2 * BN : 0;
+    constexpr int TABF = GN ? 2 * BM : 0;
+    static_assert(SMEM % 4 == 0 && SSLF % 4 == 0, "16-byte aligned LDS regions");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM + SSLF + TABF];
+    // (scale, shift) rows: written once at kernel start, read by the store loop; per-row scene slot / scale-shift row
+    float* const ssl = smem + SMEM;
+    int* const rowsc = reinterpret_cast<int*>(smem + SMEM + SSLF);
+    int* const rowss = rowsc + BM;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -97,12 +102,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
 
     f32x4 xr[XF], wr[WF];
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.0f;
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
@@ -187,18 +186,116 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     const int64_t scene0 = (int64_t)rb * spt;                 // blocks are scene-aligned
     const bool has_ss = GN && p.scale_shift != nullptr;
     const bool ss_lds = has_ss && (p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX) && scenes_here <= SSL_MAX;
-    load_tile(0);
+    // IL == 2: operand tiles go from global memory straight into the swizzled LDS stage (buffer_load_dwordx4 ... lds, 1 KiB = 8
+    // rows x 128 B per wave instruction): no staging registers, no ds_write pass, no per-tile address arithmetic -- a wave's
+    // chunks have fixed per-lane byte offsets (voffset) and the K position moves in the scalar offset.  The LDS image is
+    // lane-linear, so the XOR swizzle is applied on the global side: lane (row r, slot q') fetches k-quad q' ^ ((r >> 1) & 7).
+    constexpr int CH = (BM + BN) / 8;             // 1-KiB chunks per tile
+    constexpr int NI = (CH + NW - 1) / NW;        // chunks per wave (a ragged last round re-fetches chunks 0.. : same bytes)
+    int dvoff[IL == 2 ? NI : 1];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const float* const xb1 = a1 + row0 * p.lda1;
+    const float* const xb2 = a2 ? a2 + row0 * p.lda2 : xb1;
+    const float* const wb = w + (int64_t)col0 * p.ldw;
+    if constexpr (IL == 2) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int c = wave_u + NW * i;
+            if (c >= CH) c -= CH;
+            const int q = (lane & 7) ^ ((((c & 1) << 2) + (lane >> 4)) & 7);
+            const bool isx = c < BM / 8;
+            const int r = (isx ? c : c - BM / 8) * 8 + (lane >> 3);
+            const bool ok = isx ? r < rows_here : col0 + r < p.n;
+            dvoff[i] = (ok ? r : 0) * (int)(isx ? p.lda1 : p.ldw) * 4 + q * 16;          // host guarantees lda1 == lda2
+        }
+    }
+    auto dma_tile = [&](int kt, float* stage) {
+        if constexpr (IL == 2) {
+            const int k0 = kt * BK;
+            const bool seg1 = k0 < p.k1;
+            const float* const xb = seg1 ? xb1 : xb2;
+            const int sx = (seg1 ? k0 : k0 - p.k1) * 4, sw = k0 * 4;
+            __attribute__((address_space(3))) char* lbase = (__attribute__((address_space(3))) char*)stage;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int c = wave_u + NW * i;
+                if (c >= CH) c -= CH;
+                const bool isx = c < BM / 8;               // wave-uniform: scalar selects, no branch
+#if defined(__HIP_DEVICE_COMPILE__)                        // (the host pass of hipcc has no buffer-resource builtins)
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(isx ? xb : wb), 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lbase + c * 1024, 16, dvoff[i], isx ? sx : sw, 0, 0);
+#else
+                (void)isx; (void)sx; (void)sw; (void)xb; (void)lbase;
+#endif
+            }
+        }
+    };
+    if constexpr (IL == 2) dma_tile(0, smem);
+    else load_tile(0);
+    // per-row tables of the GroupNorm epilogue (scene slot, scale/shift row): built here, under the first operand tile's
+    // latency, so that the epilogue has no integer division, no conditioning-mode branches and one barrier fewer
+    if constexpr (GN) {
+        for (int t = tid; t < BM; t += T) {
+            const int sc = t / N;
+            const bool ok = t < rows_here;
+            rowsc[t] = ok ? sc : 0;
+            // PER_SCENE / BY_INDEX rows are staged in ssl (the host only picks tiles with <= SSL_MAX scenes for those modes)
+            rowss[t] = !ok ? 0 : (p.ss_mode == DSC_SS_PER_SLOT ? t - sc * N : (int)(row0 + t));
+        }
+    }
     if constexpr (GN) {
         if (ss_lds) {
+            // all index loads, then all value loads, then the LDS writes: three unrolled passes so the round trips overlap
+            int64_t srow[SSV];
+            int soff[SSV];
 #pragma unroll
             for (int j = 0; j < SSV; ++j) {
                 const int f = tid + T * j;                     // (scene, half, column) flattened
                 const int sc = f / (2 * BN), hc = f % (2 * BN);
-                if (sc < scenes_here) {
-                    const int64_t row = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + sc : p.ss_index[scene0 + sc];
-                    ssl[f] = p.scale_shift[row * p.ld_ss + (hc >= BN ? p.n : 0) + col0 + (hc % BN)];
-                }
+                const int scc = sc < scenes_here ? sc : 0;     // slots past the block's scenes re-stage scene 0 (never read)
+                srow[j] = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + scc : p.ss_index[scene0 + scc];
+                soff[j] = (hc >= BN ? p.n : 0) + col0 + (hc % BN);
             }
+            float sval[SSV];
+#pragma unroll
+            for (int j = 0; j < SSV; ++j) sval[j] = p.scale_shift[srow[j] * p.ld_ss + soff[j]];
+#pragma unroll
+            for (int j = 0; j < SSV; ++j) ssl[tid + T * j] = sval[j];
+        }
+    }
+    // IL kernels start the accumulators at the bias (the loads land under the first operand tile) instead of adding it after
+    // the main loop, where 16 dependent L2 round trips sat exposed at the top of the epilogue
+    {
+        const bool bvec = IL && bias && (col0 + BN <= p.n) && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = col0 + (wn * TN + tn) * 32 + 8 * q + 4 * half;
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (bvec) b4 = *reinterpret_cast<const f32x4*>(bias + c);
+                else if (IL && bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bv = bias[c + e < p.n ? c + e : 0];        // clamped address: no branch per element
+                        b4[e] = c + e < p.n ? bv : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn][4 * q + e] = b4[e];
+            }
+    }
+    // GroupNorm affine of this lane's 4 columns per column tile (epilogue layout): 8 registers per tile, loaded once here
+    f32x4 gab[GN ? 2 * TN : 1];
+    if constexpr (GN) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int c = col0 + (wn * TN + tn) * 32 + (lane & 7) * 4;
+            gab[2 * tn] = *reinterpret_cast<const f32x4*>(p.gamma + c);
+            gab[2 * tn + 1] = *reinterpret_cast<const f32x4*>(p.beta + c);
         }
     }
     // Outputs leave through LDS (see the epilogue); the flags are needed before the main loop because the residual prefetch
@@ -228,7 +325,98 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             }
         }
     };
-    if constexpr (IL) {
+    if constexpr (IL == 2) {
+        static_assert(BK == 32, "IL: BK = 32 (8 quads per row)");
+        constexpr int S = BK / 8;
+        constexpr int MM = TM * TN * 4;           // MFMAs per group
+        static_assert(S == 4 && MM >= TM + TN + NI, "IL: the MFMA groups are too short to carry the staging instructions");
+        const int swz = (l31 >> 1) & 7;
+        int foff[S];                              // float offset of this lane's fragment quad for each 8-wide K step
+#pragma unroll
+        for (int k8 = 0; k8 < S; ++k8) foff[k8] = (((k8 * 2 + half) ^ swz) << 2);
+        f32x4 xfA[TM], wfA[TN], xfB[TM], wfB[TN];
+        auto frags = [&](const float* stage, int k8, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
+            const float* Xs = stage;
+            const float* Ws = stage + BM * BK;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                xf[tm] = *reinterpret_cast<const f32x4*>(Xs + ((wm * TM + tm) * 32 + l31) * BK + foff[k8]);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                wf[tn] = *reinterpret_cast<const f32x4*>(Ws + ((wn * TN + tn) * 32 + l31) * BK + foff[k8]);
+        };
+        auto mma = [&](const f32x4 (&xf)[TM], const f32x4 (&wf)[TN], int j0, int j1) {
+#pragma unroll
+            for (int j = j0; j < j1; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tn][j], xf[tm][j], acc[tm][tn], 0, 0, 0);
+        };
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): tile 0 is in LDS stage 0 (this wave's chunks)
+        __syncthreads();
+        DSC_STAMP(1);
+        frags(smem, 0, xfA, wfA);
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* cur = smem + (kt & 1) * IL_STAGE;
+            float* nxt = smem + ((kt + 1) & 1) * IL_STAGE;
+            __builtin_amdgcn_sched_barrier(0);
+            // group 0: MFMAs(A), the fragment reads of group 1, the DMA of tile kt+1 into the other stage (its last reader
+            // passed the barrier of tile kt-1)
+            frags(cur, 1, xfB, wfB);
+            if constexpr (PROBE != 1) dma_tile(kt + 1 < nk ? kt + 1 : nk - 1, nxt);
+            mma(xfA, wfA, 0, 4);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM - (TM + TN) - NI, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // groups 1, 2: MFMAs with the fragment reads of the following group
+            frags(cur, 2, xfA, wfA);
+            mma(xfB, wfB, 0, 4);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM - 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags(cur, 3, xfB, wfB);
+            mma(xfA, wfA, 0, 4);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM - 2 * (TM + TN), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 3: MFMAs(B); in its middle: this wave's DMA retired (vmcnt), the block barrier (every wave's chunks of
+            // tile kt+1 are in LDS, every read of tile kt has returned), then the first fragment reads of tile kt+1
+            mma(xfB, wfB, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0), lgkmcnt / expcnt untouched
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            frags(nxt, 0, xfA, wfA);
+            mma(xfB, wfB, 2, 4);
+#pragma unroll
+            for (int i = 0; i < TM + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MM / 2 - (TM + TN), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    } else if constexpr (IL == 1) {
         // Interleaved main loop.  One K tile = S groups of TM*TN*4 MFMAs; everything else a K tile needs -- the next group's
         // fragment reads, the LDS writes of tile kt+1 (register-staged one tile ahead), the global loads of tile kt+2 -- is
         // slotted BETWEEN the MFMAs of this wave's own instruction stream (sched_group_barrier), because the two waves of a SIMD
@@ -306,7 +494,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             __builtin_amdgcn_sched_barrier(0);
             // group 1: MFMAs(B) with the fragment reads of group 2 and the LDS writes of tile kt+1
             frags(cur, 2, xfA, wfA);
-            stage_tile(nxt);
+            if constexpr (PROBE != 1 && PROBE != 2) stage_tile(nxt);
             mma(xfB, wfB);
 #pragma unroll
             for (int i = 0; i < TM + TN; ++i) {
@@ -322,7 +510,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
             __builtin_amdgcn_sched_barrier(0);
             // group 2: MFMAs(A) with the fragment reads of group 3 and the global loads of tile kt+2
             frags(cur, 3, xfB, wfB);
-            load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
+            if constexpr (PROBE != 1 && PROBE != 2) load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
             mma(xfA, wfA);
 #pragma unroll
             for (int i = 0; i < TM + TN; ++i) {
@@ -346,7 +534,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wfB[tn][j], xfB[tm][j], acc[tm][tn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            if constexpr (PROBE != 2) __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             frags(nxt, 0, xfA, wfA);
 #pragma unroll
@@ -486,8 +674,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
 
     DSC_STAMP(2);
     // ------------------------------------------------------------------ epilogue
-    // bias
-    if (bias) {
+    // bias (classic loops; the IL kernels started from it)
+    if (!IL && bias) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -518,24 +706,31 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         constexpr int CT = BN / 32;       // 32-channel tiles in the block
         float* P = smem;                  // [CT][BM] per-token sums over the 32 channels of a tile
         float* Q = smem + CT * BM;        // [CT][BM] per-token sums of squares about the token's own mean
-        float* stat = smem + 2 * CT * BM; // [spt*G] mean, then [spt*G] rstd  (spt * G <= 80 for N >= 4)
+        f32x2* stat = reinterpret_cast<f32x2*>(smem + 2 * CT * BM);   // [spt*G] (mean, rstd); spt * G <= 80 for N >= 4
         const int nstat = scenes_here * G;
         const float inv_cnt = 1.0f / (64.0f * (float)N);
         // One pass over the accumulators (Chan's pairwise update): every lane reduces its 16 channels to (sum, centred sum
         // of squares), the two lane halves are merged, then one wave per (scene, group) merges the 2N token entries about
         // their common mean.  No E[x^2] - E[x]^2 cancellation anywhere: same quality as mean-then-variance, half the passes.
+        // Two-wide vector types: v_pk_add_f32 / v_pk_fma_f32 halve the VALU instruction count of this block.
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int tl = (wm * TM + tm) * 32 + l31;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                float s16 = 0.f;
+                f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s16 += acc[tm][tn][r];
+                for (int r = 0; r < 16; r += 2) s2 += f32x2{acc[tm][tn][r], acc[tm][tn][r + 1]};
+                const float s16 = s2[0] + s2[1];
                 const float m16 = s16 * (1.0f / 16.0f);
-                float q16 = 0.f;
+                const f32x2 m2 = {m16, m16};
+                f32x2 q2 = {0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float d = acc[tm][tn][r] - m16; q16 += d * d; }
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 d = f32x2{acc[tm][tn][r], acc[tm][tn][r + 1]} - m2;
+                    q2 += d * d;
+                }
+                const float q16 = q2[0] + q2[1];
                 const float so = __shfl_xor(s16, 32, 64), qo = __shfl_xor(q16, 32, 64);
                 const float dm = (so - s16) * (1.0f / 16.0f);
                 if (half == 0) {
@@ -564,39 +759,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                 q += Q[ct * BM + sc * N + tk] + 32.0f * d * d;
             }
             q = wave_sum(q);
-            if (lane == 0) {
-                stat[st] = mu;
-                stat[spt * G + st] = 1.0f / sqrtf(q * inv_cnt + p.eps);
-            }
+            if (lane == 0) stat[st] = f32x2{mu, 1.0f / sqrtf(q * inv_cnt + p.eps)};
         }
         __syncthreads();
         DSC_STAMP(7);
-        // Per-row tables so that the store loop below has no integer division and no conditioning-mode branches:
-        // (mean, rstd) of the row's scene for each group (reusing the partial-sum area) and the scale/shift row index
-        // (LDS-staged rows: the scene's slot in ssl; otherwise the row of the global table).
-        float* rowst = smem;                                        // [G][BM][2]
-        int* rowss = reinterpret_cast<int*>(stat + 192);            // [BM]; stat holds at most 2 * 40 * 2 floats
-        {
-            for (int t = tid; t < BM; t += T) {
-                const int sc = t / N;
-                const bool ok = t < rows_here;
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    rowst[(g * BM + t) * 2 + 0] = ok ? stat[sc * G + g] : 0.f;
-                    rowst[(g * BM + t) * 2 + 1] = ok ? stat[spt * G + sc * G + g] : 0.f;
-                }
-                int ssr = 0;
-                if (has_ss && ok) {
-                    if (ss_lds) ssr = sc;
-                    else if (p.ss_mode == DSC_SS_PER_SCENE) ssr = (int)(scene0 + sc);
-                    else if (p.ss_mode == DSC_SS_PER_SLOT) ssr = t - sc * N;
-                    else if (p.ss_mode == DSC_SS_BY_INDEX) ssr = (int)p.ss_index[scene0 + sc];
-                    else ssr = (int)(row0 + t);
-                }
-                rowss[t] = ssr;
-            }
-        }
-        __syncthreads();
         DSC_STAMP(3);
         float* zp = p.preact ? p.preact + (int64_t)z * p.sy : nullptr;
         const bool yfast = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
@@ -605,8 +771,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         for (int tn = 0; tn < TN; ++tn) {
             const int g = (wn * TN + tn) >> 1;
             const int c = col0 + (wn * TN + tn) * 32 + cq * 4;
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+            const f32x4 ga = gab[2 * tn], be = gab[2 * tn + 1];
             const int tl0 = wm * TM * 32 + tr;
             float* yp = y + (row0 + tl0) * p.ldy + c;               // running row pointers: +8 rows per step
             float* zq = zp ? zp + (row0 + tl0) * p.ld_preact + c : nullptr;
@@ -626,36 +791,35 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
                 for (int i = 0; i < 4; ++i) {
                     const int tl = tl0 + tm * 32 + 8 * i;
                     if (tl < rows_here) {
-                        const float mu = rowst[(g * BM + tl) * 2 + 0];
-                        const float rs = rowst[(g * BM + tl) * 2 + 1];
+                        const int sc = rowsc[tl];
+                        const f32x2 mr = stat[sc * G + g];
                         f32x4 v = *reinterpret_cast<const f32x4*>(patch + (tr + 8 * i) * TLD + cq * 4);
                         if (zq) *reinterpret_cast<f32x4*>(zq) = v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mu) * rs * ga[e] + be[e];
-                        if (ss_lds) {
-                            const float* ss = ssl + rowss[tl] * (2 * BN) + (wn * TN + tn) * 32 + cq * 4;
+                        // (v - mu) * rstd * gamma + beta  =  v * A + B,  A = rstd * gamma,  B = beta - mu * A  (packed pairs)
+                        const f32x2 rs2 = {mr[1], mr[1]}, mu2 = {mr[0], mr[0]};
+                        f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+                        const f32x2 a01 = rs2 * f32x2{ga[0], ga[1]}, a23 = rs2 * f32x2{ga[2], ga[3]};
+                        v01 = v01 * a01 + (f32x2{be[0], be[1]} - mu2 * a01);
+                        v23 = v23 * a23 + (f32x2{be[2], be[3]} - mu2 * a23);
+                        if (has_ss) {
+                            // rows not staged in LDS: per-slot / per-token tables, or (tiles with more scenes than ssl has
+                            // slots -- the host avoids them) the scene's row straight from the global table
+                            const float* ss = ss_lds ? ssl + sc * (2 * BN) + (wn * TN + tn) * 32 + cq * 4
+                                : ssb + (p.ss_mode == DSC_SS_PER_SCENE ? scene0 + sc
+                                         : p.ss_mode == DSC_SS_BY_INDEX ? p.ss_index[scene0 + sc] : (int64_t)rowss[tl]) * p.ld_ss;
                             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
-                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + BN);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] * (sc4[e] + 1.0f) + sh4[e];
-                        } else if (has_ss) {
-                            const float* ss = ssb + (int64_t)rowss[tl] * p.ld_ss;
-                            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
-                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + p.n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] * (sc4[e] + 1.0f) + sh4[e];
+                            const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + (ss_lds ? BN : p.n));
+                            v01 = v01 * (f32x2{sc4[0], sc4[1]} + 1.0f) + f32x2{sh4[0], sh4[1]};
+                            v23 = v23 * (f32x2{sc4[2], sc4[3]} + 1.0f) + f32x2{sh4[2], sh4[3]};
                         }
+                        v = f32x4{v01[0], v01[1], v23[0], v23[1]};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = dsc_silu_fast(v[e]);
                         if (res) {
                             if (EPF && use_pre) {
-                                const f32x4 r4 = rpre[(tn * TM + tm) * 4 + i];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                                v += rpre[(tn * TM + tm) * 4 + i];
                             } else if (rfast) {
-                                const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + (row0 + tl) * p.ldr + c);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                                v += *reinterpret_cast<const f32x4*>(res + (row0 + tl) * p.ldr + c);
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] += res[(row0 + tl) * p.ldr + c + e];

@@ -19,9 +19,11 @@ int check_common(const dsc_gemm_args* a) {
     return 0;
 }
 
-// IL: interleaved main loop (gemm_core.h) -- every tile whose MFMA groups are long enough to carry the staging instructions
-template <int TM, int TN, int WM, int WN, bool GN, bool IL = true>
-int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
+// IL: interleaved main loop (gemm_core.h) -- every tile whose MFMA groups are long enough to carry the staging instructions.
+// IL = 2 (operands DMA'd straight into LDS with fixed per-lane byte offsets) needs one row stride for both K segments and
+// 32-bit byte offsets inside a tile; anything else takes the register-staged form (IL = 1), same arithmetic.
+template <int TM, int TN, int WM, int WN, bool GN, int IL>
+int launch_il(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     constexpr int BN = 32 * TN * WN;
     const int nrb = (a->m + rows_per_blk - 1) / rows_per_blk;
     const int ncb = (a->n + BN - 1) / BN;
@@ -32,6 +34,17 @@ int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, false, 2, true, false, true, 0, IL>), grid, dim3(64 * WM * WN), 0, s, *a, ncb);
     DSC_LAUNCH_CHECK();
     return 0;
+}
+
+template <int TM, int TN, int WM, int WN, bool GN, int IL = 1>
+int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
+    if constexpr (IL == 0) {
+        return launch_il<TM, TN, WM, WN, GN, 0>(a, rows_per_blk, s);
+    } else {
+        const int64_t ld_max = a->lda1 > a->ldw ? a->lda1 : a->ldw;
+        const bool dma = (a->k2 == 0 || a->lda1 == a->lda2) && ld_max * 4 * (32 * TM * WM + 32 * TN * WN) < (int64_t(1) << 31);
+        return dma ? launch_il<TM, TN, WM, WN, GN, 2>(a, rows_per_blk, s) : launch_il<TM, TN, WM, WN, GN, 1>(a, rows_per_blk, s);
+    }
 }
 
 }  // namespace
@@ -49,7 +62,8 @@ extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = (a->n % 256) == 0;
     struct Cand { int bm, bn, id; };
-    const Cand cands[5] = {{160, 256, 0}, {160, 128, 1}, {128, 128, 2}, {96, 128, 3}, {64, 64, 4}};
+    // ties go to the earlier candidate: 160 x 128 (2 blocks per CU) measured 1 % ahead of 160 x 256 at M = 20480
+    const Cand cands[5] = {{160, 128, 1}, {160, 256, 0}, {128, 128, 2}, {96, 128, 3}, {64, 64, 4}};
     int best = -1;
     long best_cost = 0;
     for (int i = 0; i < 5; ++i) {
@@ -64,7 +78,7 @@ extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
         case 1: return launch<5, 1, 1, 4, false>(a, 160, s);
         case 2: return launch<2, 2, 2, 2, false>(a, 128, s);
         case 3: return launch<3, 1, 1, 4, false>(a, 96, s);
-        default: return launch<1, 1, 2, 2, false, false>(a, 64, s);
+        default: return launch<1, 1, 2, 2, false, 0>(a, 64, s);
     }
 }
 
@@ -88,23 +102,28 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scene-aligned tiles: a block holds floor(BM / N) whole scenes; padded rows are wasted MFMA work
     struct Cand { int bm, bn; };
-    const Cand cands[5] = {{160, 256}, {160, 128}, {128, 128}, {96, 128}, {64, 64}};
+    const Cand cands[5] = {{160, 128}, {160, 256}, {128, 128}, {96, 128}, {64, 64}};
     int best = -1;
     long best_cost = 0;
-    for (int i = 0; i < 5; ++i) {
-        if (cands[i].bm < N) continue;
-        if (cands[i].bn == 256 && (a->n % 256)) continue;
-        const int rpb = (cands[i].bm / N) * N;
-        const long c = tile_cost(a->m, rpb, a->n, cands[i].bm, cands[i].bn);
-        if (best < 0 || c < best_cost) { best = i; best_cost = c; }
-    }
+    // (scale, shift) rows addressed per scene (PER_SCENE, BY_INDEX) are staged in LDS at kernel start: the tile must not hold
+    // more scenes than the kernel has slots for (gemm_core.h SSL_MAX: 4 for the 4-wave 160 x 128 tile, 8 otherwise)
+    const bool per_scene_ss = a->ss_mode == DSC_SS_PER_SCENE || a->ss_mode == DSC_SS_BY_INDEX;
+    for (int pass = 0; pass < 2 && best < 0; ++pass)
+        for (int i = 0; i < 5; ++i) {
+            if (cands[i].bm < N) continue;
+            if (cands[i].bn == 256 && (a->n % 256)) continue;
+            if (pass == 0 && per_scene_ss && cands[i].bm / N > ((cands[i].bm == 160 && cands[i].bn == 128) ? 4 : 8)) continue;
+            const int rpb = (cands[i].bm / N) * N;
+            const long c = tile_cost(a->m, rpb, a->n, cands[i].bm, cands[i].bn);
+            if (best < 0 || c < best_cost) { best = i; best_cost = c; }
+        }
     if (best < 0) return DSC_ERANGE;
     const int rpb = (cands[best].bm / N) * N;
     switch (best) {
-        case 0: return launch<5, 1, 1, 8, true>(a, rpb, s);
-        case 1: return launch<5, 1, 1, 4, true>(a, rpb, s);
+        case 0: return launch<5, 1, 1, 4, true>(a, rpb, s);
+        case 1: return launch<5, 1, 1, 8, true>(a, rpb, s);
         case 2: return launch<2, 2, 2, 2, true>(a, rpb, s);
         case 3: return launch<3, 1, 1, 4, true>(a, rpb, s);
-        default: return launch<1, 1, 2, 2, true, false>(a, rpb, s);
+        default: return launch<1, 1, 2, 2, true, 0>(a, rpb, s);
     }
 }

@@ -14,7 +14,7 @@ extern "C" int tune_read_timing(long long* host, int nblocks) {
 
 using dsc_gemm::gemm_kernel;
 
-template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false, bool EPF = false, int PROBE = 0, bool IL = false>
+template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false, bool EPF = false, int PROBE = 0, int IL = 0>
 static int run(const dsc_gemm_args* a, hipStream_t s, int stagger) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
@@ -78,8 +78,12 @@ extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* s
         case 30: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 1>(a, s, stagger);
         case 31: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 2>(a, s, stagger);
         case 32: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 3>(a, s, stagger);
-        case 33: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, true>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, true>(a, s, stagger);
-        case 34: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, true>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, true>(a, s, stagger);
+        case 33: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, 1>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, 1>(a, s, stagger);
+        case 34: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 1>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 1>(a, s, stagger);
+        case 35: return run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 1, 1>(a, s, stagger);
+        case 36: return run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 2, 1>(a, s, stagger);
+        case 37: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
+        case 38: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
         case 25: return gn ? run_r01<5, 1, 1, 4, true, 32>(a, s) : run_r01<5, 1, 1, 4, false, 32>(a, s);
         case 26: return gn ? -1 : run_r01<5, 1, 1, 8, false, 64>(a, s);
     }
@@ -101,8 +105,10 @@ extern "C" const char* tune_name(int variant) {
         "25: ROUND-1 product 160x128 4w (git a07da01)", "26: ROUND-1 product 160x256 8w BK64 (git a07da01)",
         "27: PROBE 8w BK64: no global loads / LDS stores", "28: PROBE 8w BK64: + fragments read once", "29: PROBE 8w BK64: + no barriers",
         "30: PROBE 4w BK32: no global loads / LDS stores", "31: PROBE 4w BK32: + fragments read once", "32: PROBE 4w BK32: + no barriers",
-        "33: IL 160x256 8w BK32 interleaved staging (1 blk/CU)", "34: IL 160x128 4w BK32 interleaved staging (2 blk/CU)"};
-    return (variant >= 0 && variant < 35) ? names[variant] : nullptr;
+        "33: IL 160x256 8w BK32 interleaved staging (1 blk/CU)", "34: IL 160x128 4w BK32 interleaved staging (2 blk/CU)",
+        "35: PROBE IL 8w: no staging (wrong results)", "36: PROBE IL 8w: no staging, no barrier",
+        "37: IL2 160x256 8w LDS-DMA staging (1 blk/CU)", "38: IL2 160x128 4w LDS-DMA staging (2 blk/CU)"};
+    return (variant >= 0 && variant < 39) ? names[variant] : nullptr;
 }
 
 // ---- scene-resident layer kernel (diffuscene_amd/csrc/scene_core.h): one block of 512 threads per scene -------------
