@@ -135,10 +135,223 @@ __device__ __forceinline__ void tn_block(const TnArgs& p, const int it, const in
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// The same tile with the interleaved LDS-DMA main loop of gemm_core.h (IL == 2): full 32-token tiles go from HBM straight into
+// one of two LDS stages (buffer_load_dwordx4 ... lds, 1 KiB = 2 token rows x 512 B per wave instruction), the fragment reads of
+// step s+1 and the DMA of tile kt+1 are slotted between the MFMAs of step s, one block barrier per tile.  LDS rows are unpadded
+// (128 floats); the 32-float channel group g of token row r sits at position g ^ (r & 1), so the two token rows a fragment
+// read touches (lanes 0-31: row 2s, lanes 32-63: row 2s+1) fall into different bank halves.  A ragged last tile (tokens that
+// must contribute zeros) is staged through registers with masking, as the classic loop does.
+// -----------------------------------------------------------------------------------------------------
+constexpr int TN_OPF = TN_BK * 128;            // floats per operand per stage
+constexpr int TN_STAGE = 2 * TN_OPF;           // A rows | dY rows
+
+__device__ __forceinline__ void tn_block_dma(const TnArgs& p, const int it, const int jt, const int split, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int i0 = it * 128, j0 = jt * 128;
+    const long m_begin = (long)split * p.chunk;
+    const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
+
+    const float* ab;
+    long lda;
+    int ic, kseg;
+    if (i0 < p.k1) { ab = p.a1; lda = p.lda1; ic = i0; kseg = p.k1; }
+    else           { ab = p.a2; lda = p.lda2; ic = i0 - p.k1; kseg = p.k2; }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const bool do_bias = p.bias_out && it == 0 && tid < 128;   // the first k-tile column of blocks also owns the bias gradient
+    float bsum = 0.f;
+    // fragment addresses (floats, relative to an operand's stage): row 2s + half, channel group (w*2 + t) at position ^ half
+    int fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        fa[t] = half * 128 + ((((wi * 2 + t) ^ half) << 5) | l31);
+        fb[t] = TN_OPF + half * 128 + ((((wj * 2 + t) ^ half) << 5) | l31);
+    }
+    const int bcol = ((tid >> 5) << 5), bl = tid & 31;          // bias column sums: column tid of the dY tile
+
+    // DMA chunk c of a wave = token rows 2c, 2c+1: lanes 0-31 row 2c, lanes 32-63 row 2c+1; slot (lane & 31) of the LDS row holds
+    // the quad of channel group ((slot >> 3) ^ (row & 1))
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int va[4], vb[4];
+    {
+        const int slot = lane & 31, rpar = lane >> 5;
+        const int col = ((((slot >> 3) ^ rpar) << 3) | (slot & 7)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 2 * (wave_u + 4 * i) + rpar;
+            va[i] = (row * (int)lda + col) * 4;
+            vb[i] = (row * (int)p.ldd + col) * 4;
+        }
+    }
+    const long full_end = m_begin + ((m_end - m_begin) / TN_BK) * TN_BK;    // tokens covered by full tiles
+    auto dma_tile = [&](long m0, float* stage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // descriptors rebuilt per tile (scalar work): base = first token row of the tile, num_records = bytes up to the end of
+        // the matrix, so channel quads past a ragged K / n read the following rows (never stored) or, at the very end, zeros
+        const float* abase = ab + m0 * lda + ic;
+        const float* dbase = p.dy + m0 * p.ldd + j0;
+        const long arec = ((p.m - 1 - m0) * lda + (kseg - ic)) * 4, drec = ((p.m - 1 - m0) * p.ldd + (p.n - j0)) * 4;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, (int)arec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000);
+        __attribute__((address_space(3))) char* lb = (__attribute__((address_space(3))) char*)stage;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, lb + (wave_u + 4 * i) * 1024, 16, va[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, lb + TN_OPF * 4 + (wave_u + 4 * i) * 1024, 16, vb[i], 0, 0, 0);
+#else
+        (void)m0; (void)stage;
+#endif
+    };
+    auto bias_rows = [&](const float* stage) {
+        if (do_bias) {
+#pragma unroll
+            for (int r = 0; r < TN_BK; ++r) bsum += stage[TN_OPF + r * 128 + ((bcol ^ ((r & 1) << 5)) | bl)];
+        }
+    };
+
+    if (m_begin < full_end) {
+        float afA[2], bfA[2], afB[2], bfB[2];
+        auto frags = [&](const float* stage, int s_, float (&af)[2], float (&bf)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = stage[fa[t] + s_ * 256];
+                bf[t] = stage[fb[t] + s_ * 256];
+            }
+        };
+        auto mma = [&](const float (&af)[2], const float (&bf)[2]) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        };
+        dma_tile(m_begin, smem);
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
+        __syncthreads();
+        frags(smem, 0, afA, bfA);
+        int kt = 0;
+        for (long m0 = m_begin; m0 < full_end; m0 += TN_BK, ++kt) {
+            const float* cur = smem + (kt & 1) * TN_STAGE;
+            float* nxt = smem + ((kt + 1) & 1) * TN_STAGE;
+            const long mn = (m0 + TN_BK < full_end) ? m0 + TN_BK : m0;     // the last iteration re-fetches its own tile (unused)
+            bias_rows(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            // steps 0..7 carry the DMA of the next tile (8 instructions per wave), every step the fragment reads of the next one
+            dma_tile(mn, nxt);
+#pragma unroll
+            for (int s2 = 0; s2 < TN_BK / 4 - 1; ++s2) {
+                frags(cur, 2 * s2 + 1, afB, bfB);
+                mma(afA, bfA);
+                frags(cur, 2 * s2 + 2, afA, bfA);
+                mma(afB, bfB);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < (TN_BK / 4 - 1) * 8 - 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // last two steps: 14 (A) and 15 (B); the barrier sits between them
+            frags(cur, TN_BK / 2 - 1, afB, bfB);
+            mma(afA, bfA);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // this wave's DMA of the next tile has landed
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            frags(nxt, 0, afA, bfA);
+            mma(afB, bfB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    if (full_end < m_end) {
+        // ragged tail (< 32 tokens): register-staged with zero masking into stage 0, plain compute
+        float* As = smem;
+        float* Bs = smem + TN_OPF;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = tid + 256 * q;
+            const int r = f >> 5, c4 = (f & 31) * 4;
+            const bool mok = full_end + r < m_end;
+            const long m = mok ? full_end + r : m_begin;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ab + m * lda + ic + ((ic + c4 < kseg) ? c4 : 0));
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.dy + m * p.ldd + j0 + ((j0 + c4 < p.n) ? c4 : 0));
+            const int pos = r * 128 + ((((c4 >> 5) ^ (r & 1)) << 5) | (c4 & 31));
+            *reinterpret_cast<f32x4*>(As + pos) = (mok && ic + c4 < kseg) ? av : z;
+            *reinterpret_cast<f32x4*>(Bs + pos) = (mok && j0 + c4 < p.n) ? bv : z;
+        }
+        __syncthreads();
+        bias_rows(smem);
+#pragma unroll
+        for (int s_ = 0; s_ < TN_BK / 2; ++s_) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = smem[fa[t] + s_ * 256];
+                bf[t] = smem[fb[t] + s_ * 256];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    float* out = p.out + (long)split * p.slab;
+    const bool vec = (p.ldo & 3) == 0 && (p.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+    if (do_bias && j0 + tid < p.n) p.bias_out[(long)split * p.bias_slab + j0 + tid] = bsum;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + (wj * 2 + b) * 32 + l31;          // output row (n)
+        if (j >= p.n) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + (wi * 2 + a) * 32 + 8 * q + 4 * half;   // output column (k), 4 consecutive
+                if (vec && i + 3 < p.kvalid) {
+                    f32x4 t4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t4[e] = acc[a][b][4 * q + e];
+                    *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = t4;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[a][b][4 * q + e];
+                }
+            }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
-    __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
-    tn_block(p, blockIdx.x % p.ktiles, blockIdx.x / p.ktiles, blockIdx.y, As, Bs);
+    __shared__ __attribute__((aligned(16))) float smem[2 * TN_STAGE];
+    tn_block_dma(p, blockIdx.x % p.ktiles, blockIdx.x / p.ktiles, blockIdx.y, smem);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -160,8 +373,7 @@ __device__ __forceinline__ int tn_find_group(const dsc_tn_group* __restrict__ g,
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int count,
                                                                  const int splits, float* __restrict__ workspace) {
-    __shared__ __attribute__((aligned(16))) float As[TN_BK * TN_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[TN_BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) float smem[2 * TN_STAGE];
     // no XCD remap: groups differ wildly in length (20480 tokens vs 256), so contiguous chunks per XCD would leave some XCDs
     // idle; round-robin dispatch spreads every group over all XCDs (tiles t and t+8 of a 512 x 512 gradient share their A rows
     // in one L2, the rest of the sharing happens in the Infinity Cache)
@@ -183,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const dsc_tn_gr
         p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
         p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
     }
-    tn_block(p, local % ktiles, local / ktiles, split, As, Bs);
+    tn_block_dma(p, local % ktiles, local / ktiles, split, smem);
 }
 
 // second stage of the grouped launch when splits > 1: every block sums the slabs of its own 128 x 128 tile (fixed order)
