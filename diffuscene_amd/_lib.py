@@ -112,7 +112,6 @@ SIGNATURES = {
     "dsc_clip_coef_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     "dsc_adam_step_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     c_f32p, C.c_void_p]),
-    "dsc_scene_chain_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_ddpm_loss_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float),
                                     c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
     "dsc_copy2d_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),

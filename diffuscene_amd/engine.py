@@ -63,62 +63,7 @@ class Plan:
         self.time_table = time_table
         self.out = torch.empty((self.M, net.out_dim), device=dev, dtype=torch.float32)
         self._build()
-        self.tiled_steps = list(self.steps)     # one launch per layer (kept for measurements / comparison)
-        self.n_chains = 0
-        if self._chains_enabled():
-            self._fuse_chains()
-
-    # ---- scene-resident chains ---------------------------------------------------------------------
-    def _chains_enabled(self):
-        """Runs of consecutive 512-wide GEMM layers (a whole ResnetBlock, the MLP trunks) can run as ONE launch in which
-        every workgroup owns a scene (csrc/scene_chain.hip), selected with DSC_SCENE_CHAIN=1.  Measured at B=256, N=80:
-        the chained layers run at 108.9 TFLOP/s vs 104.6 for the tiled GN-GEMM, but the whole step is 12.40 ms vs 12.22 ms
-        (the K=1024 layers lose to the 8-wave tiled kernel and a single resident block still exposes every layer's
-        epilogue), so the one-launch-per-layer plan stays the default."""
-        import os
-        return os.environ.get("DSC_SCENE_CHAIN", "0") == "1" and self.N <= 80
-
-    def _fuse_chains(self):
-        gemm_f, gn_f = _lib.fn("dsc_gemm_f32"), _lib.fn("dsc_gemm_gn_silu_f32")
-        chain_f = _lib.fn("dsc_scene_chain_f32")
-        CHAIN_MAX = 8
-
-        def eligible(f, a):
-            if f is not gemm_f and f is not gn_f:
-                return False
-            g = a[0]._obj
-            return (g.n == 512 and g.batch == 1 and g.m == self.M and not g.preact and g.k1 % 32 == 0 and g.k2 % 32 == 0
-                    and (g.ldy % 4 == 0))
-
-        fused, run = [], []
-
-        def flush():
-            if len(run) >= 2:
-                for i in range(0, len(run), CHAIN_MAX):
-                    part = run[i:i + CHAIN_MAX]
-                    if len(part) == 1:
-                        fused.append(part[0])
-                        continue
-                    arr = (_lib.GemmArgs * len(part))()
-                    flags = (C.c_int32 * len(part))()
-                    for j, (f, a) in enumerate(part):
-                        C.memmove(C.byref(arr[j]), C.byref(a[0]._obj), C.sizeof(_lib.GemmArgs))
-                        flags[j] = 1 if f is gn_f else 0
-                    self.keep.append((arr, flags))
-                    fused.append((chain_f, (arr, flags, len(part), self.N)))
-                    self.n_chains += 1
-            else:
-                fused.extend(run)
-            run.clear()
-
-        for f, a in self.steps:
-            if eligible(f, a):
-                run.append((f, a))
-            else:
-                flush()
-                fused.append((f, a))
-        flush()
-        self.steps = fused
+        self.tiled_steps = self.steps            # one launch per layer (bench.py times the dominant kernel from these)
 
     # ---- step emitters -------------------------------------------------------------------------
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE):

@@ -330,18 +330,6 @@ int dsc_adam_step_f32(const dsc_optim_chunk* chunks, int32_t nchunks, float step
                       float bias_correction2_sqrt, float eps, float weight_decay, const float* grad_scale,
                       dsc_stream_t stream);
 
-/* ---------------------------------------------------------------------------------------------
- * Scene-resident chain: `count` (<= DSC_CHAIN_MAX) consecutive GEMM layers -- each described exactly as for dsc_gemm_f32
- * (is_gn[i] == 0) or dsc_gemm_gn_silu_f32 (is_gn[i] != 0) -- executed by ONE launch in which every workgroup owns one
- * scene (tokens_per_scene <= 80 rows) and walks the list; layer i+1 starts when the block has finished layer i, so a layer
- * may read anything an earlier layer of the chain wrote for the same scene (a ResnetBlock of denoise_net.py:178-206 is one
- * chain).  Restrictions: all layers share m; n <= 512 (== 512 for GN layers); k1, k2 multiples of 32; batch == 1; no
- * preact output.  Results equal the separate launches up to fp32 summation order (16x16x4 instead of 32x32x2 MFMA tiles).
- * ------------------------------------------------------------------------------------------- */
-#define DSC_CHAIN_MAX 8
-int dsc_scene_chain_f32(const dsc_gemm_args* ops, const int32_t* is_gn, int32_t count, int32_t tokens_per_scene,
-                        dsc_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

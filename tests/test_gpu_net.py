@@ -329,59 +329,3 @@ def test_variational_bound_diagnostics_match_reference(golden_dir):
     got = [float(r[k]) for k in ("total_bpd_b", "terms_bpd", "prior_bpd_b", "mse_bt")]
     for a, b in zip(got, g["all_kl"]):
         assert abs(a - b) <= 2e-4 * abs(b), (got, g["all_kl"])
-
-
-@pytest.mark.parametrize("B,N,name", [(3, 80, "uncond_living"), (2, 33, "uncond_bedroom"), (2, 12, "text_bedroom"),
-                                      (2, 21, "rearrange_living")])
-def test_scene_chain_plan_matches_tiled_plan(monkeypatch, B, N, name):
-    """Scene-resident chains (csrc/scene_chain.hip: whole ResnetBlocks / MLP trunks in one launch, one workgroup per scene)
-    against the one-launch-per-layer plan and against the oracle."""
-    kw = CASES[name][0]
-    net, _ = build(name)
-    eng = net.engine(dev())
-    if kw["channels"] == 5:
-        x = W.synth_noise((B, N, 5), 3, "x5") * 0.5
-        cond = W.synth_condition(B, N, CASES[name][3], seed=3, shared=False)
-    else:
-        x = W.synth_scene_batch(B, N, kw["class_dim"], 32, seed=3)
-        cond = W.synth_condition(B, N, 128, seed=3, shared=False)
-    L = CASES[name][4]
-    cross = W.synth_text_condition(B, L, kw.get("text_dim", 512), 3) if L else None
-    t = torch.tensor([(91 + 307 * i) % 1000 for i in range(B)], dtype=torch.int64)
-    args = (x.to(dev()), t.to(dev()), cond.to(dev()), cross.to(dev()) if cross is not None else None)
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("DSC_SCENE_CHAIN", mode)
-        eng.plans.clear()
-        with torch.no_grad():
-            outs[mode] = net(*args).clone()
-        plans = list(eng.plans.values())
-        assert len(plans) == 1 and (plans[0].n_chains > 0) == (mode == "1")
-        if mode == "1":
-            assert len(plans[0].steps) < len(plans[0].tiled_steps)
-    eng.plans.clear()
-    r = rel(outs["1"], outs["0"])
-    print(name, "B=%d N=%d chain vs tiled rel diff: %g" % (B, N, r))
-    assert r < 1e-5
-    with torch.no_grad():
-        ref = R.unet1d_forward(W.synth_state_dict(kw), kw, x, t, cond, cross)
-    assert rel(outs["1"], ref) < TOL
-
-
-def test_scene_chain_graph_loop_matches_reference_chain(golden_dir, monkeypatch):
-    """50-step reverse chain through the hipGraph sampler with scene chains forced on, vs the reference golden."""
-    monkeypatch.setenv("DSC_SCENE_CHAIN", "1")
-    g = np.load(os.path.join(golden_dir, "chains.npz"))
-    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
-    B, N, C = x.shape
-    net, diff = build("uncond_bedroom", time_num=50, model_mean_type="v")
-    net.engine(dev()).plans.clear()
-    from diffuscene_amd.sampler import NoiseReplay
-    seq = noise_list([(B, N, C)] * 51, 1, "chain50_")
-    buf = torch.stack(seq).to(dev())
-    with torch.no_grad():
-        s = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), condition_cross=None,
-                             noise_fn=NoiseReplay(buf), clip_denoised=True, graph=True)
-    assert any(p.n_chains > 0 for p in net.engine(dev()).plans.values())
-    net.engine(dev()).plans.clear()
-    assert rel(s, g["uncond_T50"]) < TOL

@@ -5,7 +5,7 @@
 // the intermediate activations are re-read by the CU that just wrote them.  Any run of consecutive GEMM steps of a launch
 // plan may be chained, whatever their data flow: layer i+1 starts after every wave of the block finished layer i, and
 // layers never read another scene's rows.
-#include "scene_gemm.h"
+#include "scene_gemm.h"   // tools/: round-1/2 experiment, not built into the library
 
 namespace {
 

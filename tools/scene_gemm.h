@@ -16,7 +16,7 @@
 // Measured (tools/scene_tune.py, M=20480, n=512): 2.30-2.46 us per K group (MFMA-bound 2.2), launch 110.8 us plain /
 // 112.6 us GN at K=512 vs 109.8 / 115.6 us for the tiled kernel.
 #pragma once
-#include "dsc_common.h"
+#include "../diffuscene_amd/csrc/dsc_common.h"
 
 namespace dsc_scene {
 
