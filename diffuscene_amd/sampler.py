@@ -39,9 +39,11 @@ class NoiseReplay:
 
 def _chains_for(B):
     """Independent sub-batch chains per captured step (env DSC_CHAINS, default 1).  Scenes are independent, so the batch
-    can run as several dependency chains on separate streams inside the graph.  Measured on MI355X (B=256, N=80): two
-    128-scene chains overlap fully (12.77 ms vs 16.3 ms back to back) but only match the single 256-scene chain
-    (12.81 ms) -- a lone wave per SIMD cannot use the matrix-pipe time its neighbour frees -- so it stays opt-in."""
+    can run as several dependency chains on separate streams inside the graph, optionally phase-shifted by
+    DSC_CHAIN_OFFSET_NS (a device-side delay at the head of the side chains).  Measured on MI355X (B=256, N=80,
+    tools/chain_sweep.py): with the round-1 GEMMs two 128-scene chains gained 3 % (12.07 vs 12.44 ms, offset 0; every
+    non-zero offset lost); with the interleaved LDS-DMA GEMMs one chain is best (10.73 ms vs 10.97 ms for two, 12.1 ms for
+    four) -- a single 256-scene chain already fills the CUs and leaves no launch gaps -- so it stays opt-in."""
     import os
     n = int(os.environ.get("DSC_CHAINS", "1"))
     return n if (n > 1 and B % n == 0 and B // n >= 64) else 1
@@ -49,7 +51,7 @@ def _chains_for(B):
 
 def _chain_offset_ns():
     import os
-    return int(os.environ.get("DSC_CHAIN_OFFSET_NS", "50000"))
+    return int(os.environ.get("DSC_CHAIN_OFFSET_NS", "0"))
 
 
 class _StepGraph:
