@@ -22,7 +22,8 @@ pmc) cd /tmp && export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/${TAG}_pmc_sample -o p -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_sample.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o f -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_fetch.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o w -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_write.log 2>&1
-  cd $R ;;
+  cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_pmc_sample -name "*.db" | head -1) > $O/${TAG}_sample_pmc.txt 2>&1
+  python tools/pmc_summary.py $TAG > $O/${TAG}_pmc_summary.json 2>&1; tail -25 $O/${TAG}_pmc_summary.json ;;
 *) echo "unknown step $s" ;;
 esac
 done

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""HBM traffic and MFMA-busy of the dominant kernel from the rocprofv3 PMC passes of tools/gpu_round.sh (`pmc` step):
+separate --pmc FETCH_SIZE / WRITE_SIZE / SQ passes -> profiles/<tag>_gemm_gn_hbm_traffic.json (read by bench.py's roofline).
+FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 tallies the 128-B requests of wide coalesced reads as 64 B)."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_kernel<5, 1, 1, 4, true"
+out = os.path.join(ROOT, "gpurun_out")
+
+
+def counters(sub):
+    dbs = glob.glob(os.path.join(out, "%s_%s" % (tag, sub), "**", "*.db"), recursive=True)
+    if not dbs:
+        return {}, None, 0
+    cur = sqlite3.connect(dbs[0]).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                       "group by kernel_name, counter_name").fetchall()
+    res, name, n = {}, None, 0
+    for k, c, cnt, v in rows:
+        if pat in k:
+            res[c], name, n = v, k, cnt
+    return res, name, n
+
+
+f, name, nf = counters("pmc_fetch")
+w, _, nw = counters("pmc_write")
+s, _, _ = counters("pmc_sample")
+head = None
+try:
+    head = open(os.path.join(ROOT, "GIT_HEAD")).read().strip()
+except OSError:
+    pass
+rec = {"kernel": name, "git_head": head,
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters in separate passes (tools/gpu_round.sh pmc) on "
+                 "`bench.py --mode sample --steps 3 --warmup 1`; per-dispatch averages over %d launches of the kernel "
+                 "(K=512 and K=1024 layers of the forward)" % nf}
+if f and w:
+    rec.update({"FETCH_SIZE_KB": f.get("FETCH_SIZE"), "WRITE_SIZE_KB": w.get("WRITE_SIZE"),
+                "fetch_bytes_corrected": f.get("FETCH_SIZE", 0) * 1024 * 2, "write_bytes": w.get("WRITE_SIZE", 0) * 1024,
+                "hbm_bytes_per_launch": f.get("FETCH_SIZE", 0) * 1024 * 2 + w.get("WRITE_SIZE", 0) * 1024,
+                "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md; WRITE_SIZE as reported.  Algorithmic minimum per K=512 launch: "
+                        "read A 41.9 MB + W 1 MB (+ residual 41.9 MB on the second conv of a ResnetBlock), write 41.9 MB."})
+if s:
+    rec["mfma_busy"] = dict(s)
+    if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
+        # MFMA busy is summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
+        rec["mfma_busy"]["busy_fraction_per_simd"] = round((s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (s["GRBM_GUI_ACTIVE"] / 8.0), 4)
+path = os.path.join(out, "%s_gemm_gn_hbm_traffic.json" % tag)       # copy to profiles/rNN_gemm_gn_hbm_traffic.json to publish it
+with open(path, "w") as fh:
+    json.dump(rec, fh, indent=1)
+print(json.dumps(rec, indent=1))
