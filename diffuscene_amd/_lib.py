@@ -83,6 +83,8 @@ SIGNATURES = {
     "dsc_p_sample_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                    c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "dsc_add_scalar_i64": (C.c_int, [c_i64p, C.c_int32, C.c_int64, C.c_void_p]),
+    "dsc_postfilter_compact_f32": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                             C.c_void_p, C.c_void_p]),
     "dsc_stream_delay": (C.c_int, [C.c_int64, C.c_void_p]),
     "dsc_gemm_tn_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p,
                                   C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),

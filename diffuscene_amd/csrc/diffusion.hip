@@ -71,6 +71,40 @@ __global__ __launch_bounds__(256) void complete_overwrite_kernel(float* __restri
     }
 }
 
+// Post-filter of generated scenes (reference delete_empty_from_network_samples, diffusion_scene_layout_ddpm.py:351-406): slot i
+// of a scene is dropped when its 'empty' logit (column empty_col) is >= 0.  The reference takes that decision from BATCH ROW 0
+// for every scene of the batch (:379, mode 0, kept as the drop-in default); mode 1 decides per scene, which is what batched
+// generation needs.  One block per scene: keep flags -> exclusive prefix (ballot / popcount per wave, 3 waves cover N <= 192)
+// -> kept rows move to the front in their original order, the tail is zero-filled, counts[b] = rows kept.
+__global__ __launch_bounds__(192) void postfilter_compact_kernel(const float* __restrict__ x, int n, int c, int empty_col,
+                                                                  int mode, int keep_empty, float* __restrict__ out,
+                                                                  int* __restrict__ counts) {
+    __shared__ int wave_cnt[3];
+    __shared__ int dst[192];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src_flags = x + (int64_t)(mode == 0 ? 0 : b) * n * c;
+    const bool valid = tid < n;
+    const bool keep = valid && (keep_empty || !(src_flags[(int64_t)tid * c + empty_col] >= 0.0f));
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2];
+    dst[tid] = keep ? base + before : -1;
+    __syncthreads();
+    const float* xs = x + (int64_t)b * n * c;
+    float* os = out + (int64_t)b * n * c;
+    for (int i = tid; i < n * c; i += 192) {
+        const int r = i / c, col = i - r * c;
+        const int d = dst[r];
+        if (d >= 0) os[(int64_t)d * c + col] = xs[i];
+    }
+    for (int i = total * c + tid; i < n * c; i += 192) os[i] = 0.0f;
+    if (tid == 0) counts[b] = total;
+}
+
 inline unsigned grid_x(int64_t inner) {
     int64_t g = (inner + 255) / 256;
     return (unsigned)(g > 64 ? 64 : g);
@@ -124,6 +158,19 @@ extern "C" int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(add_scalar_i64_kernel, dim3((count + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(stream), t, count, delta);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_postfilter_compact_f32(const float* samples, int32_t b, int32_t n, int32_t c, int32_t empty_col,
+                                          int32_t mode, int32_t keep_empty, float* packed, int32_t* counts,
+                                          dsc_stream_t stream) {
+    if (!samples || !packed || !counts || b < 1 || n < 1 || c < 1 || empty_col < 0 || empty_col >= c) return DSC_EINVAL;
+    if (mode < 0 || mode > 1 || samples == packed) return DSC_EINVAL;
+    if (n > 192) return DSC_ERANGE;
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(postfilter_compact_kernel, dim3(b), dim3(192), 0, static_cast<hipStream_t>(stream), samples, n, c,
+                       empty_col, mode, keep_empty, packed, counts);
     DSC_LAUNCH_CHECK();
     return 0;
 }

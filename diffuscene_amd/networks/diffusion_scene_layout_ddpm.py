@@ -276,21 +276,56 @@ class DiffusionSceneLayout_DDPM(Module):
             return torch.arange(n)
         return torch.nonzero(~empty_logit_row0, as_tuple=False).flatten()
 
-    @torch.no_grad()
-    def delete_empty_from_network_samples(self, samples, device="cpu", keep_empty=False):
-        samples = samples.detach().to("cpu")               # one device->host copy for the whole post-filter
+    def _split_boxes(self, rows):
+        """(B, K, C) kept rows -> the reference's output dict (raw class scores, :383-386; CPU tensors, :390-406)."""
         tr, sz, bb, nc = self.translation_dim, self.size_dim, self.bbox_dim, self.class_dim
-        is_empty0 = samples[0, :, bb + nc - 1] >= 0
-        keep = self._keep_rows(is_empty0, keep_empty)
         out = {
-            "class_labels": samples[:, keep, bb:bb + nc - 1].contiguous(),      # raw class scores, as the reference
-            "translations": samples[:, keep, 0:tr].contiguous(),
-            "sizes": samples[:, keep, tr:tr + sz].contiguous(),
-            "angles": samples[:, keep, tr + sz:bb].contiguous(),
+            "class_labels": rows[:, :, bb:bb + nc - 1].contiguous(),
+            "translations": rows[:, :, 0:tr].contiguous(),
+            "sizes": rows[:, :, tr:tr + sz].contiguous(),
+            "angles": rows[:, :, tr + sz:bb].contiguous(),
         }
         if self.objfeat_dim > 0:
-            out["objfeats"] = samples[:, keep, bb + nc:bb + nc + self.objfeat_dim].contiguous()
+            out["objfeats"] = rows[:, :, bb + nc:bb + nc + self.objfeat_dim].contiguous()
         return out
+
+    @torch.no_grad()
+    def delete_empty_from_network_samples(self, samples, device="cpu", keep_empty=False):
+        """Reference :351-406.  Its loop takes the keep / drop decision of every slot from BATCH ROW 0 (:379) (and only runs
+        for batch_size 1: its accumulators are (1, 0, .) tensors); here that decision is applied to the whole batch, so
+        B = 1 is exactly the reference and B > 1 returns equally long scenes.  Samples on a HIP device are compacted there
+        (dsc_postfilter_compact_f32, one launch) and cross to the host once; per-scene filtering of a batch is
+        ``delete_empty_per_scene``."""
+        samples = samples.detach()
+        bb, nc = self.bbox_dim, self.class_dim
+        if samples.is_cuda and samples.dtype == torch.float32 and samples.shape[1] <= 192:
+            from .. import ops
+            packed, counts = ops.postfilter_compact(samples.contiguous(), bb + nc - 1, per_scene=False, keep_empty=keep_empty)
+            k = int(counts[0].item())
+            return self._split_boxes(packed[:, :k].to("cpu"))
+        samples = samples.to("cpu")
+        keep = self._keep_rows(samples[0, :, bb + nc - 1] >= 0, keep_empty)
+        return self._split_boxes(samples[:, keep])
+
+    @torch.no_grad()
+    def delete_empty_per_scene(self, samples, keep_empty=False):
+        """Batched generation: every scene of ``samples`` (B, N, C) is filtered by ITS OWN 'empty' logits, i.e. the reference
+        method applied to each scene alone.  One device launch + one device->host copy; returns a list of B dicts (the
+        reference's keys, leading dimension 1)."""
+        from .. import ops
+        samples = samples.detach().contiguous()
+        packed, counts = ops.postfilter_compact(samples, self.bbox_dim + self.class_dim - 1, per_scene=True,
+                                                keep_empty=keep_empty)
+        packed, counts = packed.to("cpu"), counts.to("cpu").tolist()
+        return [self._split_boxes(packed[b:b + 1, :counts[b]]) for b in range(samples.shape[0])]
+
+    @torch.no_grad()
+    def generate_layout_batched(self, room_mask, num_points, point_dim, batch_size, text=None, clip_denoised=False,
+                                batch_seeds=None, keep_empty=False):
+        """``generate_layout`` for a whole batch: one reverse loop for ``batch_size`` scenes, each post-filtered on its own."""
+        samples = self.sample(room_mask, num_points, point_dim, batch_size, text=text, clip_denoised=clip_denoised,
+                              batch_seeds=batch_seeds)
+        return self.delete_empty_per_scene(samples, keep_empty=keep_empty)
 
     @torch.no_grad()
     def delete_empty_boxes(self, samples_dict, device="cpu", keep_empty=False):

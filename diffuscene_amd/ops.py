@@ -239,6 +239,18 @@ def add_scalar_i64(t, delta):
     return t
 
 
+def postfilter_compact(samples, empty_col, per_scene=False, keep_empty=False):
+    """(B,N,C) generated scenes -> (packed (B,N,C) with the kept slots first, counts (B,) int32); see the C header."""
+    _c(samples, "samples")
+    b, n, c = samples.shape
+    packed = torch.empty_like(samples)
+    counts = torch.empty((b,), device=samples.device, dtype=torch.int32)
+    _lib.check(_lib.fn("dsc_postfilter_compact_f32")(samples.data_ptr(), b, n, c, int(empty_col), 1 if per_scene else 0,
+                                                     1 if keep_empty else 0, packed.data_ptr(), counts.data_ptr(),
+                                                     stream_ptr()), "dsc_postfilter_compact_f32")
+    return packed, counts
+
+
 def stream_delay(ns):
     """Idle the current stream for ``ns`` nanoseconds (device-side, capturable)."""
     _lib.check(_lib.fn("dsc_stream_delay")(int(ns), stream_ptr()), "dsc_stream_delay")

@@ -152,6 +152,13 @@ int dsc_p_sample_f32(const float* x_t, const float* model_out, const float* nois
 /* In-graph timestep bookkeeping for the captured reverse loop (:365-366): t[i] += delta. */
 int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t stream);
 
+/* Post-filter of generated scenes (delete_empty_from_network_samples, diffusion_scene_layout_ddpm.py:351-406): slot i is
+ * dropped when samples[.., i, empty_col] >= 0 (and keep_empty == 0).  mode 0: the decision of batch row 0 is applied to every
+ * scene (the reference's loop, :379); mode 1: per scene.  packed (b, n, c): kept rows first, original order, zero tail;
+ * counts[b] = rows kept.  n <= 192; samples and packed must not alias. */
+int dsc_postfilter_compact_f32(const float* samples, int32_t b, int32_t n, int32_t c, int32_t empty_col, int32_t mode,
+                               int32_t keep_empty, float* packed, int32_t* counts, dsc_stream_t stream);
+
 /* Stream-ordered idle of `ns` nanoseconds (one wave on the constant 100 MHz clock; ns <= 10 ms).  No reference counterpart:
  * it sets the phase offset between the independent half-batch chains of one captured reverse step (sampler.py). */
 int dsc_stream_delay(int64_t ns, dsc_stream_t stream);

@@ -52,3 +52,57 @@ def load_reference():
     dn = _load("denoise_net", "denoise_net.py")
     dd = _load("diffusion_ddpm", "diffusion_ddpm.py")
     return loss, dn, dd
+
+
+_PARENT = "dsc_refpkg"
+
+
+def load_reference_package():
+    """Load the reference's wrapper-level modules -- networks/diffusion_scene_layout_ddpm.py and
+    networks/foldingnet_autoencoder.py -- under a synthetic parent package so that their relative imports
+    (``..stats_logger``) resolve.  Absent third-party imports are stubbed: ``clip`` and ``wandb`` (never called on the pinned
+    paths), and ``ChamferDistancePytorch.chamfer3D.dist_chamfer_3D.chamfer_3DDist`` -> the reference's own pure-torch
+    ``chamfer_python.distChamfer`` (same outputs as its CUDA extension per its unit_test.py).  Returns a dict of modules."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    key = _PARENT + ".networks.diffusion_scene_layout_ddpm"
+    if key in sys.modules:
+        return {n: sys.modules[_PARENT + ".networks." + n] for n in
+                ("loss", "denoise_net", "diffusion_ddpm", "diffusion_scene_layout_ddpm", "foldingnet_autoencoder")}
+    load_reference()                       # tkinter stubs
+    from transformers import BertModel, BertTokenizer  # noqa: F401  (import it before wandb is stubbed: accelerate probes for wandb)
+    for name in ("clip", "wandb"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+
+    def _load_file(modname, path):
+        spec = importlib.util.spec_from_file_location(modname, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        spec.loader.exec_module(m)
+        return m
+
+    cp = _load_file("dsc_ref_chamfer_python", os.path.join(REF_ROOT, "ChamferDistancePytorch", "chamfer_python.py"))
+    import torch
+
+    class chamfer_3DDist(torch.nn.Module):
+        def forward(self, a, b):
+            return cp.distChamfer(a, b)
+
+    for name in ("ChamferDistancePytorch", "ChamferDistancePytorch.chamfer3D", "ChamferDistancePytorch.chamfer3D.dist_chamfer_3D"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules["ChamferDistancePytorch.chamfer3D.dist_chamfer_3D"].chamfer_3DDist = chamfer_3DDist
+    parent = types.ModuleType(_PARENT)
+    parent.__path__ = [os.path.join(REF_ROOT, "scene_synthesis")]
+    sys.modules[_PARENT] = parent
+    _load_file(_PARENT + ".stats_logger", os.path.join(REF_ROOT, "scene_synthesis", "stats_logger.py"))
+    nets = types.ModuleType(_PARENT + ".networks")
+    nets.__path__ = [_NET_DIR]
+    sys.modules[_PARENT + ".networks"] = nets
+    out = {}
+    for mod in ("loss", "denoise_net", "diffusion_ddpm", "diffusion_scene_layout_ddpm", "foldingnet_autoencoder"):
+        out[mod] = _load_file("%s.networks.%s" % (_PARENT, mod), os.path.join(_NET_DIR, mod + ".py"))
+    return out

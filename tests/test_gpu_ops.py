@@ -1,6 +1,9 @@
 """GPU: every C-ABI kernel against a plain fp32/fp64 torch restatement of the same reference op (oracle pieces).
 Tolerances are written per test; elementwise diffusion steps must be BIT-EXACT."""
 import math
+import os
+
+import numpy as np
 
 import pytest
 import torch
@@ -235,3 +238,41 @@ def test_bad_arguments_are_rejected_not_clamped():
     v = torch.zeros(512, device=dev())
     with pytest.raises(RuntimeError, match="DSC_ERANGE"):
         ops.gemm_gn_silu(x, wz, v, v, v, 200)            # more than 160 objects per scene
+
+
+@pytest.mark.gpu
+def test_postfilter_matches_reference_method(golden_dir):
+    """Device post-filter vs the REAL reference delete_empty_from_network_samples (tests/golden/postfilter.npz, produced per
+    scene because the reference method only runs for batch_size 1): per-scene mode == the reference on every scene alone;
+    the drop-in method == the reference for B = 1 and applies row 0's decision to a larger batch; exact equality."""
+    import types
+    from oracle.make_golden_postfilter import CASES, case_samples
+    from diffuscene_amd import ops
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM as M
+    g = np.load(os.path.join(golden_dir, "postfilter.npz"))
+    for name in CASES:
+        x, nc, nf = case_samples(name)
+        me = types.SimpleNamespace(translation_dim=3, size_dim=3, angle_dim=2, bbox_dim=8, class_dim=nc, objfeat_dim=nf,
+                                   n_classes=nc + 1)
+        me._split_boxes = types.MethodType(M._split_boxes, me)
+        me._keep_rows = types.MethodType(M._keep_rows, me)
+        xd = x.to(dev())
+        for keep in (False, True):
+            per = M.delete_empty_per_scene(me, xd, keep_empty=keep)
+            assert len(per) == x.shape[0]
+            for b, d in enumerate(per):
+                for k, v in d.items():
+                    ref = torch.from_numpy(g["%s.keep%d.scene%d.%s" % (name, int(keep), b, k)])
+                    assert v.shape == ref.shape and torch.equal(v, ref), (name, keep, b, k)
+            whole = M.delete_empty_from_network_samples(me, xd, keep_empty=keep)
+            host = M.delete_empty_from_network_samples(me, x, keep_empty=keep)           # CPU tensors: the host path
+            for k, v in whole.items():
+                ref0 = torch.from_numpy(g["%s.keep%d.scene0.%s" % (name, int(keep), k)])
+                assert torch.equal(v[0:1], ref0) and torch.equal(v, host[k]), (name, keep, k)
+    # packed layout: kept rows first, zero tail, counts
+    x, nc, nf = case_samples("bedroom_b3")
+    packed, counts = ops.postfilter_compact(x.to(dev()), 8 + nc - 1, per_scene=True)
+    for b in range(x.shape[0]):
+        keep = x[b, :, 8 + nc - 1] < 0
+        assert int(counts[b]) == int(keep.sum())
+        assert torch.equal(packed[b, :int(counts[b])].cpu(), x[b][keep]) and float(packed[b, int(counts[b]):].abs().sum()) == 0.0
