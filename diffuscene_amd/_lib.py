@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffuscene_hip.so")
 
-ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_LEAKY01 = 0, 1, 2, 3
 SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
 MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
 WS_MAX = 64

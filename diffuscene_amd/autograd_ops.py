@@ -231,6 +231,25 @@ class AttentionFn(Function):
 
 
 # --------------------------------------------------------------------------------------------------------------
+def linear_any(x, weight, bias=None):
+    """nn.Linear semantics for any leading shape and any in_features on the HIP GEMM (forward and backward): the reduction
+    dimension is zero-padded to a multiple of 32 when needed (differentiable copies; these are the small conditioning layers)."""
+    lead, k = x.shape[:-1], x.shape[-1]
+    x2 = x.reshape(-1, k)
+    w2 = as2d(weight)
+    if k % 32:
+        kp = (k + 31) // 32 * 32
+        xp = torch.zeros((x2.shape[0], kp), device=x.device, dtype=x.dtype)
+        xp[:, :k] = x2
+        wp = torch.zeros((w2.shape[0], kp), device=x.device, dtype=x.dtype)
+        wp[:, :k] = w2
+        x2, w2 = xp, wp
+    elif not x2.is_contiguous() or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    y = LinearFn.apply(x2, w2, bias, None, None)
+    return y.reshape(*lead, y.shape[-1])
+
+
 def linear(a, mod, a2=None, residual=None):
     return LinearFn.apply(a, mod.weight, mod.bias, a2, residual)
 

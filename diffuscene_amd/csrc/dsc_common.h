@@ -30,6 +30,7 @@ __device__ __forceinline__ float dsc_gelu(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float dsc_act(float x, int act) {
     if (act == DSC_ACT_GELU) return dsc_gelu(x);
     if (act == DSC_ACT_SILU) return dsc_silu(x);
+    if (act == DSC_ACT_LEAKY01) return x > 0.0f ? x : 0.1f * x;
     return x;
 }
 

@@ -16,6 +16,7 @@ int check_common(const dsc_gemm_args* a) {
     if (a->k2 > 0 && (!dsc_aligned16(a->a2) || (a->lda2 & 3))) return DSC_EALIGN;
     if (a->batch > 1 && ((a->sa1 & 3) || (a->sa2 & 3) || (a->sw & 3))) return DSC_EALIGN;
     if (a->act_in != DSC_ACT_NONE) return DSC_EINVAL;      // input activations are separate launches (dsc_activation_f32)
+    if (a->act_out < DSC_ACT_NONE || a->act_out > DSC_ACT_SILU) return DSC_EINVAL;   // fused output activations: GELU / SiLU
     return 0;
 }
 

@@ -1282,6 +1282,8 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
         } else if (act == DSC_ACT_SILU) {
             const float sig = 1.0f / (1.0f + expf(-xv));
             d = sig * (1.0f + xv * (1.0f - sig));
+        } else if (act == DSC_ACT_LEAKY01) {
+            d = xv > 0.0f ? 1.0f : 0.1f;
         } else d = 1.0f;
         dx[i] = dy[i] * d;
     }

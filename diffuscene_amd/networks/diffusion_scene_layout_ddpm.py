@@ -20,9 +20,33 @@ from .denoise_net import Unet1D
 from .diffusion_ddpm import DiffusionPoint
 
 
-def _two_layer(n_in, n_out):
-    return nn.Sequential(nn.Linear(n_in, n_out, bias=False), nn.LeakyReLU(0.1, inplace=True),
+class _TwoLayer(nn.Sequential):
+    """Linear(bias=False) -> LeakyReLU(0.1) -> Linear(bias=False): the instance / partial / arrange condition MLPs of the
+    reference (:94-125).  Same parameters and state_dict keys (``0.weight``, ``2.weight``) as the reference's nn.Sequential;
+    forward and backward run on the fp32 MFMA GEMM and the elementwise HIP kernels (autograd_ops), not on ATen / rocBLAS."""
+
+    def __init__(self, n_in, n_out):
+        super().__init__(nn.Linear(n_in, n_out, bias=False), nn.LeakyReLU(0.1, inplace=True),
                          nn.Linear(n_out, n_out, bias=False))
+
+    def forward(self, x):
+        from .._lib import ACT_LEAKY01
+        from ..autograd_ops import ActFn, linear_any
+        h = linear_any(x, self[0].weight)
+        h = ActFn.apply(h.reshape(-1, h.shape[-1]).contiguous(), ACT_LEAKY01).reshape(h.shape)
+        return linear_any(h, self[2].weight)
+
+
+class _HipLinear(nn.Linear):
+    """nn.Linear whose forward / backward run on the HIP GEMM (fc_text_f, fc_room_f)."""
+
+    def forward(self, x):
+        from ..autograd_ops import linear_any
+        return linear_any(x, self.weight, self.bias)
+
+
+def _two_layer(n_in, n_out):
+    return _TwoLayer(n_in, n_out)
 
 
 class DiffusionSceneLayout_DDPM(Module):
@@ -35,12 +59,12 @@ class DiffusionSceneLayout_DDPM(Module):
         self.text_clip_embedding = config.get("text_clip_embedding", False)
         if self.room_mask_condition:
             self.feature_extractor = feature_extractor
-            self.fc_room_f = nn.Linear(self.feature_extractor.feature_size, config["latent_dim"])
+            self.fc_room_f = _HipLinear(self.feature_extractor.feature_size, config["latent_dim"])
             print('use room mask as condition')
         elif self.text_condition:
             text_embed_dim = config.get("text_embed_dim", 512)
             if self.text_glove_embedding:
-                self.fc_text_f = nn.Linear(50, text_embed_dim)
+                self.fc_text_f = _HipLinear(50, text_embed_dim)
                 print('use text as condition, and pretrained glove embedding')
             elif self.text_clip_embedding:
                 import clip
@@ -60,7 +84,7 @@ class DiffusionSceneLayout_DDPM(Module):
                     self.bertmodel = BertModel.from_pretrained("bert-base-cased")
                     for p in self.bertmodel.parameters():
                         p.requires_grad = False
-                self.fc_text_f = nn.Linear(768, text_embed_dim)
+                self.fc_text_f = _HipLinear(768, text_embed_dim)
                 print('use text as condition, and pretrained bert model')
         else:
             print('NOT use room and text as condition')

@@ -33,6 +33,7 @@ typedef void* dsc_stream_t; /* hipStream_t */
 #define DSC_ACT_NONE 0
 #define DSC_ACT_GELU 1   /* exact erf GELU (nn.GELU default) */
 #define DSC_ACT_SILU 2
+#define DSC_ACT_LEAKY01 3 /* nn.LeakyReLU(0.1): the condition MLPs of diffusion_scene_layout_ddpm.py:94-125 (elementwise kernels) */
 
 #define DSC_SS_NONE      0
 #define DSC_SS_PER_TOKEN 1   /* scale_shift row = token           (context-conditioned ResnetBlock) */

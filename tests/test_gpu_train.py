@@ -422,3 +422,38 @@ def test_grouped_weight_gradient_gemm(scale):
         assert rel(it["out"], rw) < 5e-6
         if it["dbias"] is not None:
             assert rel(it["dbias"], rb) < 5e-6
+
+
+@pytest.mark.gpu
+def test_condition_mlps_run_on_the_hip_gemm_and_match_torch():
+    """The wrapper's condition layers (reference diffusion_scene_layout_ddpm.py:94-125, :47-51): Linear -> LeakyReLU(0.1) ->
+    Linear without biases on an un-aligned input width, and the biased text projection -- forward and all gradients vs the
+    same modules evaluated by torch in fp64.  Tolerance 1e-5 relative (fp32 MFMA vs fp64)."""
+    import torch.nn as nn
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import _HipLinear, _TwoLayer
+    d = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for n_in, n_out, lead in ((60, 384, (3, 21)), (12, 128, (12,)), (65, 64, (2, 12))):
+        m = _TwoLayer(n_in, n_out).to(d)
+        assert sorted(m.state_dict()) == ["0.weight", "2.weight"]              # the reference's nn.Sequential keys
+        x = torch.randn(*lead, n_in, device=d, requires_grad=True)
+        y = m(x)
+        g = torch.randn_like(y)
+        y.backward(g)
+        ref = nn.Sequential(nn.Linear(n_in, n_out, bias=False), nn.LeakyReLU(0.1), nn.Linear(n_out, n_out, bias=False)).double()
+        ref.load_state_dict({k: v.double().cpu() for k, v in m.state_dict().items()})
+        xr = x.detach().double().cpu().requires_grad_(True)
+        yr = ref(xr)
+        yr.backward(g.double().cpu())
+        for a, b in ((y, yr), (x.grad, xr.grad), (m[0].weight.grad, ref[0].weight.grad), (m[2].weight.grad, ref[2].weight.grad)):
+            assert float((a.detach().double().cpu() - b).abs().max()) <= 1e-5 * float(b.abs().max()), (n_in, n_out)
+    lin = _HipLinear(768, 512).to(d)
+    x = torch.randn(4, 7, 768, device=d, requires_grad=True)
+    y = lin(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr = torch.nn.functional.linear(x.detach().double().cpu(), lin.weight.detach().double().cpu(), lin.bias.detach().double().cpu())
+    assert float((y.detach().double().cpu() - yr).abs().max()) <= 1e-5 * float(yr.abs().max())
+    dwr = g.double().cpu().reshape(-1, 512).t() @ x.detach().double().cpu().reshape(-1, 768)
+    assert float((lin.weight.grad.double().cpu() - dwr).abs().max()) <= 1e-5 * float(dwr.abs().max())
+    assert float((lin.bias.grad.double().cpu() - g.double().cpu().sum(dim=(0, 1))).abs().max()) <= 1e-5 * float(g.abs().sum())
