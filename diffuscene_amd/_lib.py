@@ -83,6 +83,28 @@ SIGNATURES = {
     "dsc_p_sample_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                    c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     "dsc_add_scalar_i64": (C.c_int, [c_i64p, C.c_int32, C.c_int64, C.c_void_p]),
+    "dsc_knn16_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dsc_rowsq_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int64, c_f32p, C.c_void_p]),
+    "dsc_knn_cov_f32": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
+    "dsc_gather_max_f32": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64,
+                                     C.c_void_p, C.c_void_p]),
+    "dsc_gather_max_bwd_f32": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                         C.c_int64, C.c_void_p]),
+    "dsc_bn_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32]),
+    "dsc_batchnorm_fwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_float,
+                                        C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
+                                        C.c_void_p]),
+    "dsc_batchnorm_eval_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32,
+                                         c_f32p, C.c_void_p]),
+    "dsc_batchnorm_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p,
+                                        c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
+    "dsc_rowmax_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p, C.c_void_p]),
+    "dsc_rowmax_bwd_f32": (C.c_int, [c_f32p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
+    "dsc_point_affine_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, c_f32p, C.c_void_p]),
+    "dsc_point_affine_bwd_f32": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int32, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p,
+                                           C.c_int64, C.c_void_p]),
     "dsc_postfilter_compact_f32": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                              C.c_void_p, C.c_void_p]),
     "dsc_stream_delay": (C.c_int, [C.c_int64, C.c_void_p]),

@@ -337,6 +337,49 @@ int dsc_clip_coef_f32(const double* partial, int32_t nchunks, float max_norm, fl
 int dsc_adam_step_f32(const dsc_optim_chunk* chunks, int32_t nchunks, float step_size, float beta1, float beta2,
                       float bias_correction2_sqrt, float eps, float weight_decay, const float* grad_scale,
                       dsc_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * FoldingNet KL auto-encoder (scene_synthesis/networks/foldingnet_autoencoder.py:56-390), the pieces around its 1x1
+ * convolutions (which are dsc_gemm_f32 calls).  Point features are token-major [cloud * n + point][channel].
+ * ------------------------------------------------------------------------------------------- */
+/* knn() (:59-76): the 16 nearest points of every point inside its own cloud (itself included), nearest first; idx [clouds*n][16]
+ * holds point indices inside the cloud.  dim == 3 and gram == NULL: distances from the coordinates; otherwise
+ * gram = per-cloud Gram matrices [clouds][n][n] (a batched dsc_gemm_f32 of the features with themselves) and sqnorm[rows] =
+ * squared row norms (dsc_rowsq_f32).  16 <= n <= 2048. */
+int dsc_knn16_f32(const float* x, int64_t ldx, int32_t dim, const float* gram, const float* sqnorm, int32_t clouds, int32_t n,
+                  int32_t* idx, dsc_stream_t stream);
+int dsc_rowsq_f32(const float* x, int64_t ldx, int32_t dim, int64_t rows, float* out, dsc_stream_t stream);
+/* Encoder input (:197-205): out[q][0:3] = xyz, out[q][3:12] = covariance sums of the 16 neighbours (row-major 3x3). */
+int dsc_knn_cov_f32(const float* xyz, int64_t ldx, const int32_t* idx, int32_t clouds, int32_t n, float* out, int64_t ldo,
+                    dsc_stream_t stream);
+/* GraphLayer local max pooling (:160-165) and its backward (dx must be zero-filled; fp32 atomic adds). */
+int dsc_gather_max_f32(const float* x, int64_t ldx, const int32_t* idx, int32_t clouds, int32_t n, int32_t ch, float* out,
+                       int64_t ldo, uint8_t* arg, dsc_stream_t stream);
+int dsc_gather_max_bwd_f32(const float* dy, int64_t ldy, const int32_t* idx, const uint8_t* arg, int32_t clouds, int32_t n,
+                           int32_t ch, float* dx_zeroed, int64_t lddx, dsc_stream_t stream);
+/* nn.BatchNorm1d over the rows of x [rows][ch] (+ ReLU when relu != 0).  Training form: batch statistics (biased variance for
+ * the normalisation, unbiased for running_var; running_* may be NULL), xhat (may be NULL) and y dense [rows][ch];
+ * workspace >= dsc_bn_workspace_floats(rows, ch).  Eval form: mean / rstd given.  Backward: dense dy, xhat, y. */
+int64_t dsc_bn_workspace_floats(int64_t rows, int32_t ch);
+int dsc_batchnorm_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int64_t rows, int32_t ch, float eps,
+                          float momentum, int32_t relu, float* mean, float* rstd, float* running_mean, float* running_var,
+                          float* xhat, float* y, float* workspace, int64_t workspace_floats, dsc_stream_t stream);
+int dsc_batchnorm_eval_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, int64_t rows, int32_t ch, int32_t relu, float* y, dsc_stream_t stream);
+int dsc_batchnorm_bwd_f32(const float* dy, const float* xhat, const float* y, const float* gamma, const float* rstd, int64_t rows,
+                          int32_t ch, int32_t relu, float* dx, float* dgamma, float* dbeta, float* workspace,
+                          int64_t workspace_floats, dsc_stream_t stream);
+/* Global max pooling over the points of a cloud (:219): out [clouds][ch], arg = first point attaining it; backward dense. */
+int dsc_rowmax_f32(const float* x, int64_t ldx, int32_t clouds, int32_t n, int32_t ch, float* out, int32_t* arg,
+                   dsc_stream_t stream);
+int dsc_rowmax_bwd_f32(const float* dy, const int32_t* arg, int32_t clouds, int32_t n, int32_t ch, float* dx, dsc_stream_t stream);
+/* First convolution of a FoldingLayer (:247-251) on cat([x | codeword]) without the cat:
+ * y[b*n + p][c] = sum_{k<d} wp[c][k] * x[row][k] + t[b][c], row = p (x_per_cloud == 0: the shared 2-D grid) or b*n + p, d <= 4,
+ * t = Wc . codeword + bias from the GEMM.  Backward: dx (optional), dwp [ch][d], dt [clouds][ch]. */
+int dsc_point_affine_f32(const float* x, int64_t ldx, int32_t x_per_cloud, const float* wp, int64_t ldw, const float* t,
+                         int32_t clouds, int32_t n, int32_t ch, int32_t d, float* y, dsc_stream_t stream);
+int dsc_point_affine_bwd_f32(const float* dy, const float* x, int64_t ldx, int32_t x_per_cloud, const float* wp, int64_t ldw,
+                             int32_t clouds, int32_t n, int32_t ch, int32_t d, float* dx, int64_t lddx, float* dwp, int64_t lddw,
+                             float* dt, float* workspace, int64_t workspace_floats, dsc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -221,3 +221,37 @@ TEXT_BEDROOM = dict(dim=512, dim_mults=[1, 1, 1, 1], channels=62, objectness_dim
 REARRANGE_LIVING = dict(dim=512, dim_mults=[1, 1, 1, 1], channels=5, objectness_dim=0, class_dim=25,
                         angle_dim=2, objfeat_dim=32, self_condition=True, context_dim=0,
                         instanclass_dim=512, modulate_time_context_instanclass=True)
+
+
+def synth_module_state(module, seed=0):
+    """Deterministic, well-conditioned values for every parameter / buffer of ``module`` (used for the FoldingNet auto-encoder,
+    whose reference and HIP implementations share parameter names): conv / linear weights ~ N(0, 1/fan_in), biases ~ 0.05 N,
+    BatchNorm gain 1 + 0.1 N, shift 0.1 N, running_var in [1, 1.1); keyed by the parameter NAME, not by creation order."""
+    sd = {}
+    for name, t in module.state_dict().items():
+        g = _gen("ae." + name, seed)
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.zeros_like(t)
+        elif name.endswith("running_var"):
+            sd[name] = 1.0 + 0.1 * torch.rand(t.shape, generator=g)
+        elif name.endswith("running_mean"):
+            sd[name] = 0.05 * torch.randn(t.shape, generator=g)
+        elif t.dim() >= 2:
+            fan_in = t.shape[1]
+            sd[name] = torch.randn(t.shape, generator=g) / (fan_in ** 0.5)
+        elif ".bn" in name or name.split(".")[-2].startswith("bn") or "layers.1." in name or "layers.4." in name:
+            sd[name] = (1.0 + 0.1 * torch.randn(t.shape, generator=g)) if name.endswith("weight") else 0.1 * torch.randn(t.shape, generator=g)
+        else:
+            sd[name] = 0.05 * torch.randn(t.shape, generator=g)
+    return sd
+
+
+def synth_point_clouds(B, N, seed=0):
+    """(B, N, 3) clouds: points on noisy boxes of different extents (shape-like, not isotropic noise)."""
+    g = _gen("ae.points", seed)
+    ext = 0.15 + 0.3 * torch.rand(B, 1, 3, generator=g)
+    p = (torch.rand(B, N, 3, generator=g) - 0.5) * 2.0
+    face = torch.randint(0, 3, (B, N), generator=g)
+    sign = torch.sign(torch.rand(B, N, generator=g) - 0.5)
+    p.scatter_(2, face[..., None], sign[..., None])
+    return (p * ext + 0.01 * torch.randn(B, N, 3, generator=g)).contiguous()
