@@ -58,6 +58,10 @@ class TnGroup(C.Structure):
                 ("ws_offset", C.c_int64)]
 
 
+class ColsumItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("m", C.c_int32), ("n", C.c_int32), ("out", C.c_void_p)]
+
+
 class WsBwdItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dw_std", C.c_void_p), ("dw", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
@@ -114,6 +118,7 @@ SIGNATURES = {
     "dsc_gemm_tn_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_int64,
                                           C.c_void_p]),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
+    "dsc_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
                                       c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_float, C.c_void_p]),

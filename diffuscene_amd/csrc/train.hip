@@ -502,6 +502,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
                                                               (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+
+// Grouped column sums: out_i[c] = sum_r x_i[r][c] for MANY small matrices in one launch (the per-scene partials of the bias /
+// GroupNorm-affine / LayerNorm-gain gradients: one [scenes][n] matrix per layer, 80+ per training step).  blockIdx.y = item,
+// blockIdx.x = 64-column slab; the block walks all rows (m is a few hundred), 8 loads in flight per thread.
+struct ColsumItem { const float* x; long ldx; int m, n; float* out; };
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumItem* __restrict__ items) {
+    __shared__ float red[4][64];
+    const ColsumItem it = items[blockIdx.y];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (blockIdx.x * 64 >= it.n) return;
+    const int rq = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < it.n) {
+        const float* xp = it.x + (long)rq * it.ldx + c;
+        const long step = 4 * it.ldx;
+        int r = rq;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; r + 28 < it.m; r += 32, xp += 8 * step) {
+            const float v0 = xp[0], v1 = xp[step], v2 = xp[2 * step], v3 = xp[3 * step];
+            const float v4 = xp[4 * step], v5 = xp[5 * step], v6 = xp[6 * step], v7 = xp[7 * step];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        for (; r < it.m; r += 4, xp += step) s0 += xp[0];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[rq][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rq == 0 && c < it.n) it.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // =====================================================================================================
 // Backward of the fused GroupNorm + (scale+1, shift) + SiLU epilogue.  Block = (scene b, group g): 64 channels x N tokens.
 //   z: pre-norm conv output (saved by the forward), dy: gradient of the block output.
@@ -1549,6 +1580,16 @@ extern "C" int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n,
     DSC_LAUNCH_CHECK();
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, (long)n, splits, out, (long)n);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_colsum_grouped_f32(const dsc_colsum_item* items_dev, int32_t count, int32_t max_n, dsc_stream_t stream) {
+    if (!items_dev || count < 1 || max_n < 1) return DSC_EINVAL;
+    static_assert(sizeof(dsc_colsum_item) == sizeof(ColsumItem), "dsc_colsum_item layout");
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(colsum_grouped_kernel, dim3((max_n + 63) / 64, count), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const ColsumItem*>(items_dev));
     DSC_LAUNCH_CHECK();
     return 0;
 }

@@ -237,6 +237,19 @@ class HipBackend:
         op = out.data_ptr()
         return self._with_scratch(64 * n, lambda wp, wn: (fn, (xp, ldx, m, n, op, wp, wn), "dsc_colsum_f32"))
 
+    def colsum_grouped(self, pairs):
+        """pairs: [(x [m, n] with contiguous rows, out [n] contiguous)] -> ONE launch."""
+        import numpy as np
+        arr = (self.lib.ColsumItem * len(pairs))()
+        max_n = 0
+        for i, (x, out) in enumerate(pairs):
+            xp, ldx = self._mat(x)
+            assert out.is_contiguous() and out.numel() == x.shape[1]
+            arr[i].x, arr[i].ldx, arr[i].m, arr[i].n, arr[i].out = xp, ldx, x.shape[0], x.shape[1], out.data_ptr()
+            max_n = max(max_n, x.shape[1])
+        table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+        return self._call("dsc_colsum_grouped_f32", table.data_ptr(), len(pairs), max_n, keep=(table, pairs))
+
     def gn_bwd(self, z, dy, gamma, beta, ss, ss_mode, dz, part, dss, scenes, n_tok):
         zp, ldz = self._mat(z)
         dp, ldy = self._mat(dy)
@@ -345,6 +358,7 @@ class TrainPlan:
         self._cur = self.fwd
         self.bwd_writes = []              # (index of the LAST step of a backward op, (G offset, length)) per finished gradient
         self._tn_pending = []             # deferred weight-gradient GEMMs (leaves of the backward): one grouped launch
+        self._cs_pending = []             # deferred column sums of per-scene gradient partials: one grouped launch
         self.n_adds = 0
         C_in = net.channels
         dev = self.device
@@ -507,7 +521,25 @@ class TrainPlan:
         self._tn_pending.append({"a": a, "dy": dy, "out": out, "a2": a2, "kvalid": kvalid, "dbias": dbias,
                                  "params": tuple(p for p in params if p is not None), "after": after})
 
+    def colsum_later(self, x, out, params=(), after=None):
+        """out = column sums of x, deferred into the next grouped launch (flush_tn): leaves of the backward, like the weight
+        gradients.  Backends without a grouped form run it in place."""
+        if not hasattr(self.be, "colsum_grouped"):
+            self.emit(self.be.colsum(x, out))
+            if after is not None:
+                after()
+            self.wrote(*params)
+            return
+        self._cs_pending.append({"x": x, "out": out, "params": tuple(params), "after": after})
+
     def flush_tn(self):
+        cs, self._cs_pending = self._cs_pending, []
+        if cs:
+            self.emit(self.be.colsum_grouped([(it["x"], it["out"]) for it in cs]))
+            for it in cs:
+                if it["after"] is not None:
+                    it["after"]()
+            self.wrote(*[p for it in cs for p in it["params"]])
         items, self._tn_pending = self._tn_pending, []
         if not items:
             return
@@ -630,13 +662,14 @@ class TrainPlan:
             self.emit(self.be.gn_bwd(z, dy, norm.weight, norm.bias, ss, ss_mode, dz, part, dss_arg, scenes, self.N))
             o_b, o_g, o_be = (self.flat.grad_range(p)[0] for p in (conv.bias, norm.weight, norm.bias))
             if o_g == o_b + D and o_be == o_g + D:
-                self.emit(self.be.colsum(part, self.flat.G[o_b:o_b + 3 * D]))
+                self.colsum_later(part, self.flat.G[o_b:o_b + 3 * D], params=(conv.bias, norm.weight, norm.bias))
             else:
                 tmp = self.new(1, 3 * D)
-                self.emit(self.be.colsum(part, tmp.view(-1)))
-                for i, p in enumerate((conv.bias, norm.weight, norm.bias)):
-                    self.emit(self.be.copy(self.flat.grad_view(p).view(1, D), tmp[:, i * D:(i + 1) * D]))
-            self.wrote(conv.bias, norm.weight, norm.bias)
+
+                def scatter(tmp=tmp):
+                    for i, p in enumerate((conv.bias, norm.weight, norm.bias)):
+                        self.emit(self.be.copy(self.flat.grad_view(p).view(1, D), tmp[:, i * D:(i + 1) * D]))
+                self.colsum_later(part, tmp.view(-1), params=(conv.bias, norm.weight, norm.bias), after=scatter)
             if slot_tmp is not None:
                 red = self.new(self.N, 2 * D)
                 self.emit(self.be.colsum(slot_tmp.view(scenes, self.N * 2 * D), red.view(-1)))
@@ -672,8 +705,7 @@ class TrainPlan:
             nblk = min((M_ + 3) // 4, 512)
             part = self.new(nblk, x.t.shape[1])
             self.g_write(x, lambda dst: self.emit(self.be.layernorm_bwd(x.t, g, dy, dst, part)))
-            self.emit(self.be.colsum(part, self.flat.grad_view(gain).view(-1)))
-            self.wrote(gain)
+            self.colsum_later(part, self.flat.grad_view(gain).view(-1), params=(gain,))
             if residual is not None:
                 self.g_alias(residual, dy)
         self._tape.append(bw)

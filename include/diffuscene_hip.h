@@ -209,6 +209,11 @@ int dsc_gemm_tn_grouped_f32(const dsc_tn_group* groups_dev, int32_t count, int32
 int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,
                    int64_t workspace_floats, dsc_stream_t stream);
 
+/* Grouped column sums: out_i[c] = sum_r x_i[r][c] for `count` small matrices in ONE launch (items: a DEVICE array; every m
+ * should be a few hundred rows -- the per-scene partials of bias / affine gradients).  Fixed summation order. */
+typedef struct dsc_colsum_item { const float* x; int64_t ldx; int32_t m, n; float* out; } dsc_colsum_item;
+int dsc_colsum_grouped_f32(const dsc_colsum_item* items_dev, int32_t count, int32_t max_n, dsc_stream_t stream);
+
 /* Backward of the GroupNorm + (scale+1, shift) + SiLU epilogue of dsc_gemm_gn_silu_f32 (Block.forward,
  * denoise_net.py:167-176) from the saved pre-norm output z.  dz feeds the GEMM backward; dgamma_p / dbeta_p /
  * dbias_p are per-scene partials, row b at p + b*partial_stride (reduce with dsc_colsum_f32); dss is [scenes][1024] for

@@ -30,6 +30,9 @@ gns = [int(x) for x in opt("--gn", "0,1").split(",")]
 ks = [int(x) for x in opt("--k", "512,1024").split(",")]
 B, N = int(opt("--batch", "256")), int(opt("--objects", "80"))
 nores = "--nores" in sys.argv
+if opt("--stagger", None) is not None:
+    lib.tune_set_stagger(int(opt("--stagger", "0")))
+    print("stagger: the second resident block of every CU starts %s cycles late" % opt("--stagger", "0"))
 dev = torch.device("cuda:0")
 M = B * N
 torch.manual_seed(0)

@@ -84,6 +84,8 @@ extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* s
         case 36: return run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 2, 1>(a, s, stagger);
         case 37: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
         case 38: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
+        case 39: return gn ? run<3, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<3, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
+        case 40: return gn ? run<2, 2, 2, 2, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<2, 2, 2, 2, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
         case 25: return gn ? run_r01<5, 1, 1, 4, true, 32>(a, s) : run_r01<5, 1, 1, 4, false, 32>(a, s);
         case 26: return gn ? -1 : run_r01<5, 1, 1, 8, false, 64>(a, s);
     }
@@ -107,8 +109,9 @@ extern "C" const char* tune_name(int variant) {
         "30: PROBE 4w BK32: no global loads / LDS stores", "31: PROBE 4w BK32: + fragments read once", "32: PROBE 4w BK32: + no barriers",
         "33: IL 160x256 8w BK32 interleaved staging (1 blk/CU)", "34: IL 160x128 4w BK32 interleaved staging (2 blk/CU)",
         "35: PROBE IL 8w: no staging (wrong results)", "36: PROBE IL 8w: no staging, no barrier",
-        "37: IL2 160x256 8w LDS-DMA staging (1 blk/CU)", "38: IL2 160x128 4w LDS-DMA staging (2 blk/CU)"};
-    return (variant >= 0 && variant < 39) ? names[variant] : nullptr;
+        "37: IL2 160x256 8w LDS-DMA staging (1 blk/CU)", "38: IL2 160x128 4w LDS-DMA staging (2 blk/CU)",
+        "39: IL2 96x128 4w LDS-DMA", "40: IL2 128x128 4w (2x2 tiles) LDS-DMA"};
+    return (variant >= 0 && variant < 41) ? names[variant] : nullptr;
 }
 
 // ---- scene-resident layer kernel (diffuscene_amd/csrc/scene_core.h): one block of 512 threads per scene -------------
