@@ -48,6 +48,20 @@ int launch(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     }
 }
 
+// out[r][c] = sum_s slabs[s][r][c] (+ bias[c]) (+ residual[r][c]); fixed summation order
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab, int nslab, const float* __restrict__ bias,
+                                     const float* __restrict__ residual, long ldr, float* __restrict__ out, long ldo, int m, int n) {
+    const long total = (long)m * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n), c = (int)(i - (long)r * n);
+        float acc = 0.f;
+        for (int s2 = 0; s2 < nslab; ++s2) acc += slabs[(long)s2 * slab + i];
+        if (bias) acc += bias[c];
+        if (residual) acc += residual[(long)r * ldr + c];
+        out[(long)r * ldo + c] = acc;
+    }
+}
+
 }  // namespace
 
 // Tile choice: estimated time ~ ceil(blocks / 256 CUs) * tile area (every CU works through its blocks); ties go to the
@@ -127,4 +141,36 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
         case 3: return launch<3, 1, 1, 4, true>(a, rpb, s);
         default: return launch<1, 1, 2, 2, true, 0>(a, rpb, s);
     }
+}
+
+// Split-K form for short, deep products (m <= 512 rows, K >= 1024: the time / context MLP layers of the training step, where
+// an output-tile-parallel launch has 4..128 blocks each walking K serially -- 52 us for a 2 GFLOP product).  The K range is cut
+// into `splits` equal parts that run as the batch dimension of ONE dsc_gemm_f32 launch into workspace slabs [splits][m][n];
+// a second kernel sums the slabs in a fixed order and applies bias / residual.  No output activation, single K segment.
+extern "C" int dsc_gemm_splitk_f32(const dsc_gemm_args* a, int32_t splits, float* workspace, int64_t workspace_floats,
+                                   dsc_stream_t stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (splits < 2 || splits > 64 || !workspace) return DSC_EINVAL;
+    if (a->batch != 1 || a->k2 != 0 || a->act_out != DSC_ACT_NONE) return DSC_EINVAL;
+    if (a->k1 % (BK * splits)) return DSC_EINVAL;
+    if (workspace_floats < (int64_t)splits * a->m * a->n) return DSC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15) || (((int64_t)a->m * a->n) & 3)) return DSC_EALIGN;
+    dsc_gemm_args p = *a;
+    const int kc = a->k1 / splits;
+    p.k1 = kc;
+    p.batch = splits;
+    p.sa1 = kc; p.sw = kc; p.sa2 = 0; p.sbias = 0; p.sres = 0;
+    p.bias = nullptr; p.residual = nullptr;
+    p.y = workspace; p.ldy = a->n; p.sy = (int64_t)a->m * a->n;
+    rc = dsc_gemm_f32(&p, stream);
+    if (rc) return rc;
+    const long total = (long)a->m * a->n;
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), workspace,
+                       (long)a->m * a->n, splits, a->bias, a->residual, (long)a->ldr, a->y, (long)a->ldy, a->m, a->n);
+    DSC_LAUNCH_CHECK();
+    return 0;
 }

@@ -88,6 +88,16 @@ class HipBackend:
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE):
         from . import ops
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
+        m, K = a.shape
+        # short, deep products (time / context MLPs: m = B or N rows, K >= 1024): split K over the batch dimension
+        tiles = ((m + 63) // 64) * ((out.shape[1] + 63) // 64)        # output tiles: fewer than CUs -> parallelise K instead
+        if a2 is None and act_out == ACT_NONE and tiles < 256 and K >= 1024 and (m * out.shape[1]) % 4 == 0:
+            splits = next((s for s in (8, 4, 2) if K % (32 * s) == 0 and K // s >= 128), 0)
+            if splits:
+                fn = self.lib.fn("dsc_gemm_splitk_f32")
+                self.keep.append((g, a, w, out, bias, residual))
+                floats = splits * m * out.shape[1]
+                return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
         return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual))
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):

@@ -82,6 +82,11 @@ int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
  * groups are 64 channels wide (nn.GroupNorm(8, 512)), m a multiple of tokens_per_scene <= 160. */
 int dsc_gemm_gn_silu_f32(const dsc_gemm_args* args, dsc_stream_t stream);
 
+/* Split-K form of dsc_gemm_f32 for short, deep products (few rows, K >= 1024): the K range is cut into `splits` equal parts
+ * (k1 % (32 * splits) == 0) computed as the batch dimension of one launch into workspace slabs [splits][m][n], then summed in a
+ * fixed order with bias / residual applied.  Restrictions: batch == 1, k2 == 0, act_out == DSC_ACT_NONE. */
+int dsc_gemm_splitk_f32(const dsc_gemm_args* a, int32_t splits, float* workspace, int64_t workspace_floats, dsc_stream_t stream);
+
 /* Small-K linear for un-aligned inputs (first layer of _encoder_mlp on slices of the (B,N,C)
  * tensor, denoise_net.py:487,513-524; init_conv of the 5-channel re-arrangement model, :397):
  *   y[m][n] = act( sum_k x[m*ldx + k] * w[n*ldw + k] + bias[n] ),  k_in <= 64. */

@@ -154,7 +154,9 @@ def test_train_on_batch_plan_equals_autograd_training(tmp_path, monkeypatch):
             monkeypatch.delenv("DSC_TRAIN_PLAN")
             assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (rnd_, i, la, lb)
         worst = max(_relnorm(p, q) for p, q in zip(ma.parameters(), mb.parameters()))
-        assert worst < 1e-5, worst
+        # the two paths sum some products in different fp32 orders (the plan's split-K time-MLP GEMMs, grouped reductions);
+        # Adam's g / sqrt(v) normalisation passes relative gradient differences straight into the parameters
+        assert worst < 5e-5, worst
         with torch.no_grad():                         # engine path with derived weights cached across optimizer steps
             out = ma.diffusion.model(x, t, ma._instance_condition(8, dev()), None)
         assert _relnorm(out, fresh_forward(ma)) < 1e-6, "stale derived weights after FusedAdam steps"
