@@ -12,11 +12,11 @@
 // same block, so GroupNorm (64 channels x N tokens of one scene, denoise_net.py:164) is computed from the
 // accumulators: the whole Block.forward (WS-conv + GroupNorm + scale/shift + SiLU, :167-176) is one kernel.
 //
-// Tiling: 256 threads = 4 waves; block tile BM tokens x 128 channels; BK = 32 staged through LDS with a
-// padded row stride of 36 floats (ds_read_b128 of 16 rows is bank-conflict-free: 36*r mod 64 hits 16
-// distinct 4-bank slots).  A lane reads 4 consecutive k (one ds_read_b128) per fragment and feeds 4 MFMAs
-// (lanes 0-31 carry k..k+3, lanes 32-63 carry k+4..k+7: the k-permutation is the same for both operands).
-// Register-staged prefetch of tile kt+1 overlaps the MFMAs of tile kt; two blocks per CU cover barriers.
+// Tiling: 4 or 8 waves, each TM x TN tiles of 32 x 32; BK = 32 K elements per LDS stage; a lane reads 4 consecutive k (one
+// ds_read_b128) per fragment and feeds 4 MFMAs (lanes 0-31 carry k..k+3, lanes 32-63 carry k+4..k+7: the k-permutation is the
+// same for both operands).  Main loop (IL = 2): two LDS stages filled by buffer_load ... lds straight from global memory,
+// fragments double-buffered in registers, every non-MFMA instruction of a K tile slotted between its MFMAs, one block barrier
+// per K tile -- see the comments at the loop and DESIGN.md section 4.
 
 #include <type_traits>
 #include "dsc_common.h"
@@ -34,14 +34,17 @@ extern __device__ int g_dsc_stagger;      // cycles by which the second resident
 
 namespace dsc_gemm {
 
-// TM x TN : 32x32 MFMA tiles per wave;  WM x WN : waves per block (4 or 8);  BK : K elements per staged tile;
-// DB : double-buffered LDS (one barrier per K tile);  MINW : min waves per SIMD for __launch_bounds__;
-// XCD : remap block ids so the column blocks that share a token tile run on the same XCD (shared L2).
-// PIPE (needs DB): MFMA fragments are software-pipelined one 8-wide K step ahead in registers, across the single
-// barrier per K tile, so one wave per SIMD can keep the matrix pipe busy on its own.
-template <int TM, int TN, int WM, int WN, bool GN, int BK = 32, bool DB = false, int MINW = 2, bool XCD = false,
-          bool PIPE = false, bool EPF = false, int PROBE = 0, int IL = 0>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm_args p, const int ncolblk) {
+// TM x TN : 32x32 MFMA tiles per wave;  WM x WN : waves per block (4 or 8);  BK = 32 K elements per staged tile.
+// IL : main loop -- 2 = interleaved, operands DMA'd straight into swizzled LDS stages (the product form), 1 = interleaved,
+//      register-staged (operands with two row strides / offsets beyond 32 bits), 0 = classic single-buffered loop (64 x 64 tiles
+//      whose MFMA groups are too short to carry the staging instructions).
+// PROBE : tools/gemm_tune.hip only -- attribution probes of the main loop (wrong results on purpose).
+// Always on (round-1 measurements): block ids remapped so the column blocks sharing a token tile run on one XCD (shared L2);
+// the residual quads of the epilogue requested at its top; two waves per SIMD.
+template <int TM, int TN, int WM, int WN, bool GN, int IL = 0, int PROBE = 0>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_args p, const int ncolblk) {
+    constexpr int BK = 32;
+    constexpr bool EPF = true;
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int NW = WM * WN;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
     constexpr int SSL_MAX = (IL && NW == 4 && BM + BN > 256) ? 4 : 8;   // 2 blocks per CU: 2 x (stages + tables) <= 160 KB
     constexpr int EPI = (GN ? 2 * (BN / 32) * BM + 512 : (BN / 32) * BM + 512) + NW * 32 * 36;
     constexpr int IL_STAGE = (BM + BN) * BK;  // IL: unpadded rows, XOR-swizzled 16-byte slots, two stages
-    constexpr int MAINF = IL ? 2 * IL_STAGE : (DB ? 2 : 1) * STAGE;
+    constexpr int MAINF = IL ? 2 * IL_STAGE : STAGE;
     constexpr int SMEM = (MAINF > EPI) ? MAINF : EPI;
     // ONE __shared__ object (a second one makes hipcc drain the LDS-DMA queue before every fragment read):
     // [ operand stages / epilogue scratch | (scale, shift) rows of the block's scenes | per-row tables of the GN epilogue ]
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
 
     const int z = blockIdx.y;
     int bid = blockIdx.x;
-    if (XCD) {
+    {
         const int nb = gridDim.x;
         if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // XCD x gets the contiguous chunk [x*nb/8, (x+1)*nb/8)
     }
@@ -553,86 +556,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_kernel(const dsc_gemm
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-    } else if constexpr (PIPE) {
-        static_assert(DB, "PIPE needs the double-buffered LDS stages");
-        constexpr int S = BK / 8;                 // 8-wide K steps per staged tile
-        static_assert(S == 2 || S == 4, "BK must be 16 or 32");
-        f32x4 xfA[TM], wfA[TN], xfB[TM], wfB[TN];
-        auto frags = [&](const float* stage, int k8, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
-            const float* Xs = stage;
-            const float* Ws = stage + BM * LDT;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                xf[tm] = *reinterpret_cast<const f32x4*>(Xs + ((wm * TM + tm) * 32 + l31) * LDT + k8 * 8 + half * 4);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                wf[tn] = *reinterpret_cast<const f32x4*>(Ws + ((wn * TN + tn) * 32 + l31) * LDT + k8 * 8 + half * 4);
-        };
-        auto mma = [&](const f32x4 (&xf)[TM], const f32x4 (&wf)[TN]) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tn][j], xf[tm][j], acc[tm][tn], 0, 0, 0);
-        };
-        store_tile(smem);
-        __syncthreads();
-        DSC_STAMP(1);
-        // branch-free, schedule-pinned pipeline: the compiler otherwise sinks the prefetches next to their uses and waits on
-        // them immediately (seen in the ISA); clamped tile indices make the last iterations re-stage the final tile
-        load_tile(nk > 1 ? 1 : 0);
-        frags(smem, 0, xfA, wfA);
-        for (int kt = 0; kt < nk; ++kt) {
-            const float* cur = smem + (kt & 1) * STAGE;
-            float* nxt = smem + ((kt + 1) & 1) * STAGE;
-            if constexpr (S == 4) {
-                frags(cur, 1, xfB, wfB);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(xfA, wfA);
-                __builtin_amdgcn_sched_barrier(0);
-                frags(cur, 2, xfA, wfA);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(xfB, wfB);
-                __builtin_amdgcn_sched_barrier(0);
-                frags(cur, 3, xfB, wfB);
-                store_tile(nxt);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(xfA, wfA);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-                load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
-                frags(nxt, 0, xfA, wfA);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(xfB, wfB);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                frags(cur, 1, xfB, wfB);
-                store_tile(nxt);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(xfA, wfA);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-                load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
-                frags(nxt, 0, xfA, wfA);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(xfB, wfB);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-    } else if constexpr (DB) {
-        // one barrier per K tile: tile kt+1 is written into the other LDS stage while tile kt is being consumed
-        store_tile(smem);
-        __syncthreads();
-        DSC_STAMP(1);
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) load_tile(kt + 1);
-            compute_tile(smem + (kt & 1) * STAGE);
-            if (kt + 1 < nk) store_tile(smem + ((kt + 1) & 1) * STAGE);
-            __syncthreads();
-        }
     } else if constexpr (PROBE > 0) {
         // tools/gemm_tune.hip only -- attribution probes of the main loop (results are wrong on purpose):
         //   1: no global loads / LDS stores after the first tile   2: + fragments read once   3: + no barriers

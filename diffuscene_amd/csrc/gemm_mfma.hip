@@ -32,7 +32,7 @@ int launch_il(const dsc_gemm_args* a, int rows_per_blk, hipStream_t s) {
     // XCD-aware block order: the column blocks sharing a token tile run on one XCD and hit its L2; EPF: residual
     // quads are requested at the top of the epilogue (measured -3..-6 % per launch with a residual input)
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, false, 2, true, false, true, 0, IL>), grid, dim3(64 * WM * WN), 0, s, *a, ncb);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, IL>), grid, dim3(64 * WM * WN), 0, s, *a, ncb);
     DSC_LAUNCH_CHECK();
     return 0;
 }

@@ -14,12 +14,12 @@ extern "C" int tune_read_timing(long long* host, int nblocks) {
 
 using dsc_gemm::gemm_kernel;
 
-template <int TM, int TN, int WM, int WN, bool GN, int BK, bool DB, int MINW, bool XCD, bool PIPE = false, bool EPF = false, int PROBE = 0, int IL = 0>
-static int run(const dsc_gemm_args* a, hipStream_t s, int stagger) {
+template <int TM, int TN, int WM, int WN, bool GN, int IL, int PROBE = 0>
+static int run(const dsc_gemm_args* a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int rpb = GN ? (BM / a->tokens_per_scene) * a->tokens_per_scene : BM;
     const int nrb = (a->m + rpb - 1) / rpb, ncb = (a->n + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, BK, DB, MINW, XCD, PIPE, EPF, PROBE, IL>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, GN, IL, PROBE>), dim3(nrb * ncb, a->batch), dim3(64 * WM * WN), 0, s, *a, ncb);
     return (int)hipGetLastError();
 }
 
@@ -33,61 +33,31 @@ static int run_r01(const dsc_gemm_args* a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-#define VP(id, TM, TN, WM, WN, BK, MINW) \
-    case id: return gn ? run<TM, TN, WM, WN, true, BK, true, MINW, true, true>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, true, MINW, true, true>(a, s, stagger);
+#define VI(id, TM, TN, WM, WN, IL) \
+    case id: return gn ? run<TM, TN, WM, WN, true, IL>(a, s) : run<TM, TN, WM, WN, false, IL>(a, s);
 
-#define VE(id, TM, TN, WM, WN, BK, MINW) \
-    case id: return gn ? run<TM, TN, WM, WN, true, BK, false, MINW, true, false, true>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, false, MINW, true, false, true>(a, s, stagger);
-
-#define V(id, TM, TN, WM, WN, BK, DB, MINW, XCD) \
-    case id: return gn ? run<TM, TN, WM, WN, true, BK, DB, MINW, XCD>(a, s, stagger) : run<TM, TN, WM, WN, false, BK, DB, MINW, XCD>(a, s, stagger);
-
+// Variant ids are kept from the round-1/2 logs under profiles/; the double-buffered / software-pipelined template branches that
+// ids 0-22 and 24 instantiated were removed from the product header after the interleaved loops superseded them (their
+// measurements: profiles/r01_gemm_tune_variants.txt, profiles/r02_gemm_ab_round1_variants_warm.txt).
 extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* stream, int stagger);
 extern "C" int tune_launch(int variant, int gn, const dsc_gemm_args* a, void* stream) { return tune_launch2(variant, gn, a, stream, 0); }
-extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* stream, int stagger) {
+extern "C" int tune_launch2(int variant, int gn, const dsc_gemm_args* a, void* stream, int) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (variant) {
-        V(0, 5, 1, 1, 4, 32, false, 2, false)
-        V(1, 5, 1, 1, 4, 32, false, 2, true)
-        V(2, 5, 1, 1, 4, 16, true, 2, false)
-        V(3, 5, 1, 1, 4, 16, true, 2, true)
-        V(4, 5, 1, 1, 8, 32, true, 2, false)
-        V(5, 5, 1, 1, 8, 32, true, 2, true)
-        V(6, 5, 1, 1, 8, 32, false, 2, true)
-        V(7, 5, 1, 1, 8, 64, false, 2, true)
-        V(8, 5, 2, 1, 4, 32, true, 1, true)
-        V(9, 5, 1, 1, 4, 64, false, 2, true)
-        V(10, 5, 1, 1, 4, 32, true, 1, true)
-        V(11, 5, 1, 1, 8, 16, true, 2, true)
-        V(12, 5, 2, 1, 4, 16, true, 1, true)
-        VP(13, 5, 1, 1, 4, 16, 2)
-        VP(14, 5, 1, 1, 8, 32, 2)
-        VP(15, 5, 1, 1, 8, 16, 2)
-        VP(16, 5, 1, 1, 4, 32, 1)
-        VP(17, 5, 2, 1, 4, 16, 1)
-        V(18, 1, 1, 2, 2, 32, false, 4, true)
-        V(19, 2, 2, 2, 2, 32, false, 3, true)
-        V(20, 2, 1, 2, 2, 32, false, 4, true)
-        V(21, 3, 1, 1, 4, 32, false, 3, true)
-        V(22, 1, 2, 2, 2, 32, false, 4, true)
-        VE(23, 5, 1, 1, 4, 32, 2)
-        VE(24, 5, 1, 1, 8, 64, 2)
-        case 27: return run<5, 1, 1, 8, false, 64, false, 2, true, false, true, 1>(a, s, stagger);
-        case 28: return run<5, 1, 1, 8, false, 64, false, 2, true, false, true, 2>(a, s, stagger);
-        case 29: return run<5, 1, 1, 8, false, 64, false, 2, true, false, true, 3>(a, s, stagger);
-        case 30: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 1>(a, s, stagger);
-        case 31: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 2>(a, s, stagger);
-        case 32: return run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 3>(a, s, stagger);
-        case 33: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, 1>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, 1>(a, s, stagger);
-        case 34: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 1>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 1>(a, s, stagger);
-        case 35: return run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 1, 1>(a, s, stagger);
-        case 36: return run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 2, 1>(a, s, stagger);
-        case 37: return gn ? run<5, 1, 1, 8, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<5, 1, 1, 8, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
-        case 38: return gn ? run<5, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<5, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
-        case 39: return gn ? run<3, 1, 1, 4, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<3, 1, 1, 4, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
-        case 40: return gn ? run<2, 2, 2, 2, true, 32, false, 2, true, false, true, 0, 2>(a, s, stagger) : run<2, 2, 2, 2, false, 32, false, 2, true, false, true, 0, 2>(a, s, stagger);
+        VI(23, 5, 1, 1, 4, 0)
         case 25: return gn ? run_r01<5, 1, 1, 4, true, 32>(a, s) : run_r01<5, 1, 1, 4, false, 32>(a, s);
         case 26: return gn ? -1 : run_r01<5, 1, 1, 8, false, 64>(a, s);
+        case 30: return run<5, 1, 1, 4, false, 0, 1>(a, s);
+        case 31: return run<5, 1, 1, 4, false, 0, 2>(a, s);
+        case 32: return run<5, 1, 1, 4, false, 0, 3>(a, s);
+        VI(33, 5, 1, 1, 8, 1)
+        VI(34, 5, 1, 1, 4, 1)
+        case 35: return run<5, 1, 1, 8, false, 1, 1>(a, s);
+        case 36: return run<5, 1, 1, 8, false, 1, 2>(a, s);
+        VI(37, 5, 1, 1, 8, 2)
+        VI(38, 5, 1, 1, 4, 2)
+        VI(39, 3, 1, 1, 4, 2)
+        VI(40, 2, 2, 2, 2, 2)
     }
     return -1;
 }
@@ -103,7 +73,7 @@ extern "C" const char* tune_name(int variant) {
         "13: PIPE 160x128 4w BK16 (2 blk/CU)", "14: PIPE 160x256 8w BK32 (1 blk/CU)", "15: PIPE 160x256 8w BK16",
         "16: PIPE 160x128 4w BK32 (1 blk/CU)", "17: PIPE 160x256 4w(5x2) BK16 1 wave/SIMD",
         "18: 64x64 4w (many small blocks)", "19: 128x128 4w 3 waves/SIMD", "20: 128x64 4w", "21: 96x128 4w", "22: 64x128 4w",
-        "23: product 160x128 4w + epilogue residual prefetch", "24: product 160x256 8w BK64 + epilogue residual prefetch",
+        "23: classic loop 160x128 4w (round-1 structure, round-2 epilogue)", "24: product 160x256 8w BK64 + epilogue residual prefetch",
         "25: ROUND-1 product 160x128 4w (git a07da01)", "26: ROUND-1 product 160x256 8w BK64 (git a07da01)",
         "27: PROBE 8w BK64: no global loads / LDS stores", "28: PROBE 8w BK64: + fragments read once", "29: PROBE 8w BK64: + no barriers",
         "30: PROBE 4w BK32: no global loads / LDS stores", "31: PROBE 4w BK32: + fragments read once", "32: PROBE 4w BK32: + no barriers",
