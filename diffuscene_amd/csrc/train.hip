@@ -201,7 +201,9 @@ __device__ __forceinline__ void tn_block_dma(const TnArgs& p, const int it, cons
         // the matrix, so channel quads past a ragged K / n read the following rows (never stored) or, at the very end, zeros
         const float* abase = ab + m0 * lda + ic;
         const float* dbase = p.dy + m0 * p.ldd + j0;
-        const long arec = ((p.m - 1 - m0) * lda + (kseg - ic)) * 4, drec = ((p.m - 1 - m0) * p.ldd + (p.n - j0)) * 4;
+        long arec = ((p.m - 1 - m0) * lda + (kseg - ic)) * 4, drec = ((p.m - 1 - m0) * p.ldd + (p.n - j0)) * 4;
+        if (arec > 0x7fffffffL) arec = 0x7fffffffL;      // the bound only matters within 64 rows of the end of the matrix
+        if (drec > 0x7fffffffL) drec = 0x7fffffffL;
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0, (int)arec, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000);
         __attribute__((address_space(3))) char* lb = (__attribute__((address_space(3))) char*)stage;
