@@ -276,3 +276,64 @@ def test_postfilter_matches_reference_method(golden_dir):
         keep = x[b, :, 8 + nc - 1] < 0
         assert int(counts[b]) == int(keep.sum())
         assert torch.equal(packed[b, :int(counts[b])].cpu(), x[b][keep]) and float(packed[b, int(counts[b]):].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gn", [False, True])
+def test_gemm_two_segments_with_different_row_strides(gn):
+    """[a | a2] @ W^T where a2 is a column slice of a wider tensor (lda2 != lda1): the LDS-DMA main loop needs one row stride,
+    so this shape takes the register-staged interleaved loop (IL = 1); results must equal the dense case bit for bit (same
+    arithmetic order) and the fp64 product within 5e-6."""
+    from diffuscene_amd import ops
+    torch.manual_seed(0)
+    B, N, D = 3, 80, 512
+    M = B * N
+    a = torch.randn(M, 512, device=dev())
+    wide = torch.randn(M, 1024, device=dev())
+    a2v = wide[:, 256:768]                                   # stride 1024, 16-byte aligned start
+    a2d = a2v.contiguous()
+    w = torch.randn(D, 1024, device=dev()) * 0.05
+    b = torch.randn(D, device=dev())
+    if gn:
+        gamma, beta = torch.rand(D, device=dev()) + 0.5, torch.randn(D, device=dev()) * 0.1
+        y1 = ops.gemm_gn_silu(a, w, b, gamma, beta, N, a2=a2v)
+        y2 = ops.gemm_gn_silu(a, w, b, gamma, beta, N, a2=a2d)
+        z = (torch.cat([a, a2d], 1).double() @ w.double().T + b.double()).reshape(B, N, D).permute(0, 2, 1)
+        ref = F.silu(F.group_norm(z, 8, gamma.double(), beta.double(), eps=1e-5)).permute(0, 2, 1).reshape(M, D)
+    else:
+        y1 = ops.gemm(a, w, b, a2=a2v)
+        y2 = ops.gemm(a, w, b, a2=a2d)
+        ref = torch.cat([a, a2d], 1).double() @ w.double().T + b.double()
+    assert torch.equal(y1, y2)
+    assert float((y1.double() - ref).abs().max() / ref.abs().max()) < 5e-6
+
+
+@pytest.mark.gpu
+def test_splitk_gemm_and_grouped_colsum():
+    """dsc_gemm_splitk_f32 (short, deep products: K cut over the batch dimension + fixed-order slab sum with bias / residual)
+    and dsc_colsum_grouped_f32 vs fp64."""
+    import ctypes as C
+    import numpy as np
+    from diffuscene_amd import _lib, ops
+    torch.manual_seed(1)
+    for m, n, K, splits, use_res in ((256, 2048, 2048, 8, True), (80, 128, 2048, 8, False), (256, 2048, 1024, 4, True)):
+        a = torch.randn(m, K, device=dev())
+        w = torch.randn(n, K, device=dev()) / K ** 0.5
+        b = torch.randn(n, device=dev())
+        y = torch.randn(m, n, device=dev())
+        y0 = y.clone()
+        g = ops.make_gemm_args(a, w, y, b, None, y if use_res else None)
+        ws = torch.empty(splits * m * n, device=dev())
+        _lib.check(_lib.fn("dsc_gemm_splitk_f32")(C.byref(g), splits, ws.data_ptr(), ws.numel(), ops.stream_ptr()), "splitk")
+        ref = a.double() @ w.double().T + b.double() + (y0.double() if use_res else 0)
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 5e-6
+    mats = [torch.randn(256, 1536, device=dev()), torch.randn(512, 512, device=dev()), torch.randn(37, 100, device=dev())]
+    outs = [torch.empty(x.shape[1], device=dev()) for x in mats]
+    arr = (_lib.ColsumItem * len(mats))()
+    for i, (x, o) in enumerate(zip(mats, outs)):
+        arr[i].x, arr[i].ldx, arr[i].m, arr[i].n, arr[i].out = x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], o.data_ptr()
+    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev())
+    _lib.check(_lib.fn("dsc_colsum_grouped_f32")(table.data_ptr(), len(mats), 1536, ops.stream_ptr()), "colsum_grouped")
+    for x, o in zip(mats, outs):
+        ref = x.double().sum(0)
+        assert float((o.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())

@@ -76,7 +76,8 @@ def test_smallk_and_act_backward():
     assert rel(gx.grad, xd.grad) < 2e-6
 
 
-@pytest.mark.parametrize("B,N,mode,two", [(3, 80, 2, False), (5, 21, 1, False), (4, 12, 3, True), (2, 33, 0, False)])
+@pytest.mark.parametrize("B,N,mode,two", [(3, 80, 2, False), (5, 21, 1, False), (4, 12, 3, True), (2, 33, 0, False),
+                                          (2, 100, 2, True), (3, 160, 0, False)])      # N > 80: the 10-row register form
 def test_conv_gn_silu_backward(B, N, mode, two):
     from diffuscene_amd.autograd_ops import ConvGnSiluFn
     M, D = B * N, 512
