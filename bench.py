@@ -18,6 +18,7 @@ All fp32, synthetic scenes with the real encoders' value distribution (SURVEY.md
                 sampling steps followed by floor(K/2) training steps inside ONE timed region; the two rates are also
                 reported separately ("sample", "train").  `full_loop` adds the wall time of one whole 1000-step
                 p_sample_loop(graph=True) (outside the timed region).
+`--scaling strong` treats the config's batch as the GLOBAL batch (split over the ranks) instead of the per-GPU batch.
 N > 1: one process per GPU; `python bench.py --gpus N` spawns the ranks itself (torch.distributed.run, 127.0.0.1) when it
 is not already running under torchrun.  Batch sharded by rank (weak scaling: per-GPU batch fixed); sampling needs no
 collective, training all-reduces the flat gradient buffer over RCCL.  Prints ONE JSON line on rank 0.
@@ -406,6 +407,9 @@ def main():
     ap.add_argument("--mode", default=os.environ.get("DSC_BENCH_MODE", "both"), choices=["both", "sample", "train"])
     ap.add_argument("--batch", type=int, default=None, help="override the config's per-GPU batch")
     ap.add_argument("--objects", type=int, default=None, help="override the config's objects per scene")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): the config's batch per GPU; strong: the config's batch is the GLOBAL batch, split over "
+                         "the ranks (SURVEY.md 8e: B=256 global = 32 scenes per GPU at 8 GPUs, communication-dominated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true")
     args = ap.parse_args()
@@ -432,8 +436,12 @@ def main():
         spec["batch"] = args.batch
     if args.objects:
         spec["objects"] = args.objects
+    if args.scaling == "strong":
+        if spec["batch"] % ws:
+            raise SystemExit("bench.py: --scaling strong needs the global batch (%d) divisible by the ranks (%d)" % (spec["batch"], ws))
+        spec["batch"] //= ws
     B, N = spec["batch"], spec["objects"]
-    log("building model (%s: B=%d, N=%d)" % (args.config, B, N))
+    log("building model (%s: B=%d per GPU, N=%d, %s scaling)" % (args.config, B, N, args.scaling))
     model, cfg = build_model(spec, device)
     if ws > 1:
         from diffuscene_amd import ddp
@@ -488,7 +496,7 @@ def main():
             "metric": "denoiser steps/sec (%s) at B=%d, N=%d objects" % (what, B, N),
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": ws, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s (%s), B=%d scenes per GPU, N=%d, C=%d, T=1000, mode=%s"
                                    % (spec["title"], spec["yaml"], B, N, 8 + spec["class_dim"] + 32, args.mode),
                        "name": args.config, "global_batch": B * ws,
