@@ -4,7 +4,7 @@ Same constructor kwargs (reference denoise_net.py:336-362, dead ones accepted an
 ``forward(x, beta, context=None, context_cross=None)`` contract ((B,N,C) fp32, (B,) int64 -> (B,N,C)
 contiguous), and the same ``state_dict`` keys and shapes so reference checkpoints load
 unchanged.  The modules below only HOLD parameters under the reference's names; all arithmetic runs in
-hand-written HIP kernels through ``DenoiserEngine`` (inference: static launch plan) or ``train_graph``
+hand-written HIP kernels through ``DenoiserEngine`` (inference: static launch plan) or ``autograd_ops``
 (autograd over the same kernels).  There is no PyTorch/CPU fallback: a CPU input raises.
 """
 import math
@@ -221,6 +221,6 @@ class Unet1D(nn.Module):
             raise AssertionError("expected (B, N, %d) input, got %s" % (self.channels, tuple(x.shape)))
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
-            from ..train_graph import unet1d_forward_autograd
-            return unet1d_forward_autograd(self, x, beta, context, context_cross)
+            from ..autograd_ops import unet1d_train_forward
+            return unet1d_train_forward(self, x, beta, context, context_cross)
         return self.engine(x.device).forward(x, beta, context, context_cross)

@@ -462,7 +462,7 @@ class GaussianDiffusion:
         denoise_out = denoise_fn(data_t, t, condition, condition_cross)
         assert data_t.shape == data_start.shape
         assert denoise_out.shape == data_start.shape
-        from ..train_graph import diffusion_losses
+        from ..train_loss import diffusion_losses
         return diffusion_losses(self, tb, data_start, data_t, target, denoise_out, t)
 
     def _vb_terms_bpd(self, denoise_fn, data_start, data_t, t, condition, condition_cross, clip_denoised: bool,

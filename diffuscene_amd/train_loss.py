@@ -1,16 +1,10 @@
-"""Training-side graph of the DDPM step: autograd over the HIP kernels and the loss of reference p_losses.
-
-``unet1d_forward_autograd`` runs the same kernels as the inference plan but records what the hand-written
-backward kernels (csrc/train.hip) need; ``diffusion_losses`` is the loss of diffusion_ddpm.py:556-652.
-"""
+"""The training objective of reference p_losses (diffusion_ddpm.py:556-652) for the AUTOGRAD path (configurations the static
+training plan does not cover, and the tests' reference of the fused kernel): ``DdpmLossFn`` wraps the fused loss kernel
+(all loss terms + d loss / d denoise_out in one launch) as an autograd Function; ``diffusion_losses`` dispatches to it.
+The captured training graph itself lives in train_plan.py / train_step.py."""
 import torch
 
 from .networks.loss import axis_aligned_bbox_overlaps_3d
-
-
-def unet1d_forward_autograd(net, x, t, context, context_cross):
-    from .autograd_ops import unet1d_train_forward
-    return unet1d_train_forward(net, x, t, context, context_cross)
 
 
 class DdpmLossFn(torch.autograd.Function):

@@ -193,8 +193,8 @@ def _oracle_grad_norms_fp64(kw, x, t, cond, noise, names, cross=None, iou=True):
 @pytest.mark.parametrize("mean_type,iou,B,N", [("v", True, 5, 21), ("eps", True, 3, 12), ("x0", True, 2, 80), ("v", False, 4, 12)])
 def test_fused_loss_kernel_matches_torch_definition(tmp_path, mean_type, iou, B, N):
     """dsc_ddpm_loss_f32 (all loss terms + d loss / d denoise_out in one kernel) vs the torch-op definition of the same
-    loss under autograd (train_graph.diffusion_losses(fused=False)), incl. overlapping boxes and empty slots."""
-    from diffuscene_amd import train_graph as tg
+    loss under autograd (train_loss.diffusion_losses(fused=False)), incl. overlapping boxes and empty slots."""
+    from diffuscene_amd import train_loss as tg
     from diffuscene_amd.networks.diffusion_ddpm import GaussianDiffusion, get_betas
     stats = tmp_path / "dataset_stats.txt"
     stats.write_text(json.dumps(W.DATASET_STATS))
