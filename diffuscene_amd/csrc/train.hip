@@ -1436,7 +1436,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
         const float xv = x[i];
         float d;
         if (act == DSC_ACT_GELU) {
-            const float cdf = 0.5f * (1.0f + erff(xv * 0.70710678118654752440f));
+            const float cdf = 0.5f * (1.0f + dsc_erf(xv * 0.70710678118654752440f));
             const float pdf = 0.39894228040143267794f * expf(-0.5f * xv * xv);
             d = cdf + xv * pdf;
         } else if (act == DSC_ACT_SILU) {

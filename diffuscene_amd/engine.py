@@ -72,6 +72,15 @@ class Plan:
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
 
+    def gemm_batched(self, a, w, out, bias, batch, sa, sw, sy, sbias, act_out=ACT_NONE):
+        """`batch` independent products in one launch: operand / output pointers advance by (sa, sw, sy, sbias) floats per
+        problem (a, w, out, bias describe problem 0: views into the wider buffers)."""
+        g = ops.make_gemm_args(a, w, out, bias, None, None, ACT_NONE, act_out)
+        g.batch, g.sa1, g.sw, g.sy, g.sbias = batch, sa, sw, sy, sbias
+        self.keep.append((g, a, w, out, bias))
+        self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
+        return out
+
     def gemm_gn(self, a, w, out, bias, gamma, beta, a2=None, ss=None, ss_mode=SS_NONE, residual=None):
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5,
                                tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
@@ -169,17 +178,6 @@ class Plan:
         self.pool.put(a)
         return out
 
-    def mlp_in(self, seq, c0, k):
-        """_encoder_mlp on columns [c0, c0+k) of the input; returns the 1024-wide hidden (GELU'd)."""
-        M = self.M
-        h1 = self.pool.get(M, D)
-        xs = self.x_in[:, c0:c0 + k]
-        self.call("dsc_linear_smallk_f32", xs.data_ptr(), self.x_in.stride(0), k, seq[0].weight.data_ptr(), k,
-                  seq[0].bias.data_ptr(), h1.data_ptr(), D, M, D, ACT_GELU, keep=(xs, h1))
-        h2 = self.gemm(h1, seq[2].weight, self.pool.get(M, 2 * D), seq[2].bias, act_out=ACT_GELU)
-        self.pool.put(h1)
-        return h2
-
     def _build(self):
         e, net, M, B = self.eng, self.eng.net, self.M, self.B
         pool = self.pool
@@ -208,20 +206,18 @@ class Plan:
         if net.seperate_all:
             bb, nc, no, nf = net.bbox_dim, net.class_dim, net.objectness_dim, net.objfeat_dim
             emb = pool.get(M, D)
-            h2 = self.mlp_in(net.class_embedf, bb, nc)
-            self.gemm(h2, net.class_embedf[4].weight, emb, net.class_embedf[4].bias)
+            H = len(e.enc_heads)
+            h1 = pool.get(M, H * D)
+            for i, (seq, c0, k) in enumerate(e.enc_heads):            # layer 1: tiny K on un-aligned column slices
+                xs = self.x_in[:, c0:c0 + k]
+                self.call("dsc_linear_smallk_f32", xs.data_ptr(), self.x_in.stride(0), k, seq[0].weight.data_ptr(), k,
+                          seq[0].bias.data_ptr(), h1.data_ptr() + 4 * i * D, H * D, M, D, ACT_GELU, keep=(xs, h1))
+            h2 = pool.get(M, H * 2 * D)
+            self.gemm_batched(h1[:, :D], e.enc_w2[:2 * D], h2[:, :2 * D], e.enc_b2[:2 * D], H, D, 2 * D * D, 2 * D, 2 * D,
+                              act_out=ACT_GELU)
+            pool.put(h1)
+            self.gemm(h2, e.enc_w3, emb, e.enc_b3)                    # sum over the heads = one K-concatenated product
             pool.put(h2)
-            h2 = self.mlp_in(net.bbox_embedf, 0, bb)
-            self.gemm(h2, net.bbox_embedf[4].weight, emb, net.bbox_embedf[4].bias, residual=emb)
-            pool.put(h2)
-            if no > 0:
-                h2 = self.mlp_in(net.objectness_embedf, bb + nc, no)
-                self.gemm(h2, net.objectness_embedf[4].weight, emb, net.objectness_embedf[4].bias, residual=emb)
-                pool.put(h2)
-            if nf > 0:
-                h2 = self.mlp_in(net.objfeat_embedf, bb + nc + no, nf)
-                self.gemm(h2, net.objfeat_embedf[4].weight, emb, net.objfeat_embedf[4].bias, residual=emb)
-                pool.put(h2)
             x = self.gemm(emb, net.init_conv.weight, pool.get(M, D), net.init_conv.bias)
             pool.put(emb)
         else:
@@ -291,19 +287,16 @@ class Plan:
         x = xo
         # ---- output heads, written straight into the (M, C) output at their column offsets -----------
         if net.seperate_all:
+            Hd = len(e.dec_heads)
+            d1 = self.gemm(x, e.dec_w1, pool.get(M, Hd * 2 * D), e.dec_b1, act_out=ACT_GELU)
+            d2 = pool.get(M, Hd * D)
+            self.gemm_batched(d1[:, :2 * D], e.dec_w2[:D], d2[:, :D], e.dec_b2[:D], Hd, 2 * D, D * 2 * D, D, D, act_out=ACT_GELU)
+            pool.put(d1)
             col = 0
-            heads = [(net.bbox_hidden2output, net.bbox_dim), (net.class_hidden2output, net.class_dim)]
-            if net.objectness_dim > 0:
-                heads.append((net.objectness_hidden2output, net.objectness_dim))
-            if net.objfeat_dim > 0:
-                heads.append((net.objfeat_hidden2output, net.objfeat_dim))
-            for seq, width in heads:
-                d1 = self.gemm(x, seq[0].weight, pool.get(M, 2 * D), seq[0].bias, act_out=ACT_GELU)
-                d2 = self.gemm(d1, seq[2].weight, pool.get(M, D), seq[2].bias, act_out=ACT_GELU)
-                pool.put(d1)
-                self.gemm(d2, seq[4].weight, self.out[:, col:col + width], seq[4].bias)
-                pool.put(d2)
+            for i, (seq, width) in enumerate(e.dec_heads):            # layer 3: narrow outputs at their column offsets
+                self.gemm(d2[:, i * D:(i + 1) * D], seq[4].weight, self.out[:, col:col + width], seq[4].bias)
                 col += width
+            pool.put(d2)
         else:
             self.gemm(x, net.final_conv.weight, self.out, net.final_conv.bias)
 
@@ -347,6 +340,34 @@ class DenoiserEngine:
             self.c_pack_w = self.c_pack_b = None
         self.time_table = net.time_table.to(device)
         self.time_freq = net.time_freq.to(device)
+        # The per-attribute encoder / decoder MLPs (_encoder_mlp / _decoder_mlp, denoise_net.py:484-504) are independent
+        # three-layer stacks of identical shape.  One launch per layer for ALL heads instead of one per head: more tiles per
+        # launch than the CUs hold at once, so the prologue / epilogue of one tile runs under the K loop of another.
+        #   encoders: layer 2 as a batched GEMM (weights [H][1024][512]), layer 3 as ONE GEMM over the concatenated hidden
+        #             (sum over heads = K concatenation, weights [512][H*1024], biases summed)
+        #   decoders: layer 1 as ONE GEMM (same input: weights stacked [H*1024][512]), layer 2 batched ([H][512][1024]); layer 3
+        #             stays one narrow GEMM per head (a block-diagonal [C_out][H*512] form triples the serial K loop of a
+        #             latency-bound launch)
+        self.enc_heads, self.dec_heads = [], []
+        if net.seperate_all:
+            bb, nc, no, nf = net.bbox_dim, net.class_dim, net.objectness_dim, net.objfeat_dim
+            self.enc_heads = [(net.class_embedf, bb, nc), (net.bbox_embedf, 0, bb)]
+            self.dec_heads = [(net.bbox_hidden2output, bb), (net.class_hidden2output, nc)]
+            if no > 0:
+                self.enc_heads.append((net.objectness_embedf, bb + nc, no))
+                self.dec_heads.append((net.objectness_hidden2output, no))
+            if nf > 0:
+                self.enc_heads.append((net.objfeat_embedf, bb + nc + no, nf))
+                self.dec_heads.append((net.objfeat_hidden2output, nf))
+            H, Hd = len(self.enc_heads), len(self.dec_heads)
+            self.enc_w2 = torch.empty((H * 2 * D, D), device=device)
+            self.enc_b2 = torch.empty((H * 2 * D,), device=device)
+            self.enc_w3 = torch.empty((D, H * 2 * D), device=device)
+            self.enc_b3 = torch.empty((D,), device=device)
+            self.dec_w1 = torch.empty((Hd * 2 * D, D), device=device)
+            self.dec_b1 = torch.empty((Hd * 2 * D,), device=device)
+            self.dec_w2 = torch.empty((Hd * D, 2 * D), device=device)
+            self.dec_b2 = torch.empty((Hd * D,), device=device)
 
     def _signature(self):
         """Order-sensitive fingerprint of (version, pointer) of every parameter + the epoch counter of raw-pointer
@@ -372,6 +393,18 @@ class DenoiserEngine:
                 for i, rb in enumerate(self.c_blocks):
                     self.c_pack_w[i * 2 * D:(i + 1) * 2 * D].copy_(rb.mlp[1].weight)
                     self.c_pack_b[i * 2 * D:(i + 1) * 2 * D].copy_(rb.mlp[1].bias)
+            if self.enc_heads:
+                H2 = 2 * D
+                for i, (seq, _, _) in enumerate(self.enc_heads):
+                    self.enc_w2[i * H2:(i + 1) * H2].copy_(seq[2].weight.view(H2, D))
+                    self.enc_b2[i * H2:(i + 1) * H2].copy_(seq[2].bias)
+                    self.enc_w3[:, i * H2:(i + 1) * H2].copy_(seq[4].weight.view(D, H2))
+                self.enc_b3.copy_(torch.stack([seq[4].bias for seq, _, _ in self.enc_heads]).sum(0))
+                for i, (seq, width) in enumerate(self.dec_heads):
+                    self.dec_w1[i * H2:(i + 1) * H2].copy_(seq[0].weight.view(H2, D))
+                    self.dec_b1[i * H2:(i + 1) * H2].copy_(seq[0].bias)
+                    self.dec_w2[i * D:(i + 1) * D].copy_(seq[2].weight.view(D, H2))
+                    self.dec_b2[i * D:(i + 1) * D].copy_(seq[2].bias)
         self.sig = sig
         self._ss_table_sig = None          # the per-timestep table is stale now (recomputed in place on demand)
 

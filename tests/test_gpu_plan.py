@@ -153,10 +153,13 @@ def test_train_on_batch_plan_equals_autograd_training(tmp_path, monkeypatch):
             lb = train_on_batch(mb, ob, s, tcfg)
             monkeypatch.delenv("DSC_TRAIN_PLAN")
             assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (rnd_, i, la, lb)
-        worst = max(_relnorm(p, q) for p, q in zip(ma.parameters(), mb.parameters()))
-        # the two paths sum some products in different fp32 orders (the plan's split-K time-MLP GEMMs, grouped reductions);
-        # Adam's g / sqrt(v) normalisation passes relative gradient differences straight into the parameters
-        assert worst < 5e-5, worst
+        # the two paths sum some products in different fp32 orders (the plan's split-K time-MLP GEMMs, grouped reductions), and
+        # Adam's g / sqrt(v) normalisation passes relative gradient differences straight into the parameters.  Conv biases in
+        # front of a GroupNorm have a true gradient of ZERO (the norm removes the mean): their computed gradient is rounding noise
+        # that Adam turns into +-lr steps, so 1-D tensors are only held to the size of such a random walk.
+        for (name, p), q in zip(ma.named_parameters(), mb.parameters()):
+            tol = 1e-4 if p.dim() >= 2 else 2e-3
+            assert _relnorm(p, q) < tol, (name, _relnorm(p, q))
         with torch.no_grad():                         # engine path with derived weights cached across optimizer steps
             out = ma.diffusion.model(x, t, ma._instance_condition(8, dev()), None)
         assert _relnorm(out, fresh_forward(ma)) < 1e-6, "stale derived weights after FusedAdam steps"
