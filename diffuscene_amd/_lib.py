@@ -71,6 +71,7 @@ SIGNATURES = {
     "dsc_version": (C.c_int, []),
     "dsc_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_gn_silu_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_splitk_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_linear_smallk_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

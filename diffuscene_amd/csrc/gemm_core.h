@@ -41,10 +41,13 @@ namespace dsc_gemm {
 // PROBE : tools/gemm_tune.hip only -- attribution probes of the main loop (wrong results on purpose).
 // Always on (round-1 measurements): block ids remapped so the column blocks sharing a token tile run on one XCD (shared L2);
 // the residual quads of the epilogue requested at its top; two waves per SIMD.
-template <int TM, int TN, int WM, int WN, bool GN, int IL = 0, int PROBE = 0>
+// LNF : the block spans ALL n output channels (gridDim = row blocks only) and the epilogue applies the channel LayerNorm of
+//       denoise_net.py:93-102 to every token row -- y = (acc - mean) * rsqrt(var + eps) * gain (+ residual): the out-projection
+//       of LinearAttention followed by its LayerNorm and the residual of the PreNorm block in one launch.
+template <int TM, int TN, int WM, int WN, bool GN, int IL = 0, int PROBE = 0, bool LNF = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_args p, const int ncolblk) {
     constexpr int BK = 32;
-    constexpr bool EPF = true;
+    constexpr bool EPF = !LNF;                 // LNF: 96 accumulator + 96 prefetch registers would not fit next to the LayerNorm state
     constexpr int BM = 32 * TM * WM;
     constexpr int BN = 32 * TN * WN;
     constexpr int NW = WM * WN;
@@ -762,6 +765,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
             }
         }
     } else if (fast) {
+        // LNF: per-token mean / variance over the n channels = over this lane's TN * 16 registers, its partner half (lane ^ 32)
+        // and the WN waves of the block (two passes: mean, then the centred sum of squares -- as the reference / ATen do)
+        float ln_mu[LNF ? TM : 1], ln_rs[LNF ? TM : 1];
+        f32x4 ln_g[LNF ? TN : 1];
+        if constexpr (LNF) {
+            static_assert(!GN && WM == 1, "LNF: one row of waves spans all output channels");
+            float* Pl = smem;                       // [WN][BM]
+            const float inv_n = 1.0f / (float)p.n;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    float s_ = 0.f;
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float d = pass ? acc[tm][tn][r] - ln_mu[tm] : acc[tm][tn][r];
+                            s_ += pass ? d * d : d;
+                        }
+                    s_ += __shfl_xor(s_, 32, 64);
+                    if (half == 0) Pl[wn * BM + tm * 32 + l31] = s_;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    float t_ = 0.f;
+#pragma unroll
+                    for (int w_ = 0; w_ < WN; ++w_) t_ += Pl[w_ * BM + tm * 32 + l31];
+                    if (pass == 0) ln_mu[tm] = t_ * inv_n;
+                    else ln_rs[tm] = 1.0f / sqrtf(t_ * inv_n + p.eps);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                ln_g[tn] = *reinterpret_cast<const f32x4*>(p.gamma + col0 + (wn * TN + tn) * 32 + cq * 4);
+        }
         // one copy of the store loop per output activation: the erf-GELU polynomial must not sit (branched over) in the
         // plain store path
         auto plain_store = [&](auto act_tag) {
@@ -779,7 +820,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
                 for (int q = 0; q < 4; ++q) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dsc_act(acc[tm][tn][4 * q + e], ACT);
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = LNF ? (acc[tm][tn][4 * q + e] - ln_mu[tm]) * ln_rs[tm] : dsc_act(acc[tm][tn][4 * q + e], ACT);
                     *reinterpret_cast<f32x4*>(patch + l31 * TLD + 8 * q + 4 * half) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -788,6 +830,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
                     const int tl = tl0 + tm * 32 + 8 * i;
                     if (tl < rows_here) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(patch + (tr + 8 * i) * TLD + cq * 4);
+                        if constexpr (LNF) v *= ln_g[tn];
                         if (res) {
                             const f32x4 r4 = (EPF && use_pre) ? rpre[(tn * TM + tm) * 4 + i]
                                                               : *reinterpret_cast<const f32x4*>(rp);

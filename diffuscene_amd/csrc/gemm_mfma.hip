@@ -174,3 +174,23 @@ extern "C" int dsc_gemm_splitk_f32(const dsc_gemm_args* a, int32_t splits, float
     DSC_LAUNCH_CHECK();
     return 0;
 }
+
+// y = LayerNorm_channels([a | a2] @ W^T + bias) * gain (+ residual): the out-projection + LayerNorm (+ PreNorm residual) of
+// LinearAttention / LinearAttentionCross (denoise_net.py:216-235, :98-102) in one launch.  Blocks of 96 token rows span all
+// n = 512 channels (8 waves x (3 x 2) tiles, LDS-DMA interleaved main loop), so the per-token statistics stay inside the block.
+extern "C" int dsc_gemm_layernorm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->n != 512 || a->batch != 1 || a->act_out != DSC_ACT_NONE || !a->gamma) return DSC_EINVAL;
+    if (!dsc_aligned16(a->gamma) || !dsc_aligned16(a->y) || (a->ldy & 3)) return DSC_EALIGN;
+    if (a->residual && (!dsc_aligned16(a->residual) || (a->ldr & 3))) return DSC_EALIGN;
+    if (a->bias && !dsc_aligned16(a->bias)) return DSC_EALIGN;
+    const int64_t ld_max = a->lda1 > a->ldw ? a->lda1 : a->ldw;
+    if (!(a->k2 == 0 || a->lda1 == a->lda2) || ld_max * 4 * (96 + 512) >= (int64_t(1) << 31)) return DSC_ERANGE;
+    const int nrb = (a->m + 95) / 96;
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL((gemm_kernel<3, 2, 1, 8, false, 2, 0, true>), dim3((unsigned)nrb, 1), dim3(512), 0,
+                       static_cast<hipStream_t>(stream), *a, 1);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}

@@ -100,6 +100,23 @@ class Plan:
                   out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], 1e-5, keep=(x, g, out, residual))
         return out
 
+    def out_proj_ln(self, a, conv, ln_gain, residual):
+        """to_out = Conv1d + LayerNorm of LinearAttention (:216-219) and the PreNorm block's residual.  Large batches: ONE launch
+        (dsc_gemm_layernorm_f32: blocks of 96 token rows span all 512 channels, the LayerNorm runs in the GEMM epilogue); with
+        fewer than 160 row blocks that kernel would leave CUs idle, so small batches keep GEMM + layernorm launches."""
+        M = self.M
+        out = self.pool.get(M, D)
+        if (M + 95) // 96 >= 160:
+            g = ops.make_gemm_args(a, conv.weight, out, conv.bias, None, residual, gamma=ln_gain.view(-1), beta=ln_gain.view(-1),
+                                   eps=1e-5)
+            self.keep.append((g, a, conv.weight, out, conv.bias, residual, ln_gain))
+            self.steps.append((_lib.fn("dsc_gemm_layernorm_f32"), (C.byref(g),)))
+            return out
+        o = self.gemm(a, conv.weight, self.pool.get(M, D), conv.bias)
+        self.layernorm(o, ln_gain, out, residual=residual)
+        self.pool.put(o)
+        return out
+
     # ---- network pieces ------------------------------------------------------------------------
     def resblock(self, rb, x, x2, ss, ss_mode):
         e, M = self.eng, self.M
@@ -140,10 +157,8 @@ class Plan:
         self.call("dsc_linear_attention_f32", qkv.data_ptr(), 3 * HID, qkv.data_ptr() + 4 * HID, 3 * HID,
                   qkv.data_ptr() + 8 * HID, 3 * HID, a.data_ptr(), HID, B, N, N, float(att.scale), keep=(qkv, a))
         self.pool.put(qkv)
-        o = self.gemm(a, att.to_out[0].weight, self.pool.get(M, D), att.to_out[0].bias)
+        out = self.out_proj_ln(a, att.to_out[0], att.to_out[1].g, x)
         self.pool.put(a)
-        out = self.layernorm(o, att.to_out[1].g, self.pool.get(M, D), residual=x)
-        self.pool.put(o)
         return out
 
     def crossattn(self, blk, x):
@@ -158,10 +173,8 @@ class Plan:
                   2 * HID, a.data_ptr(), HID, B, N, L, float(att.scale), keep=(q, kv, a))
         self.pool.put(q)
         self.pool.put(kv)
-        o = self.gemm(a, att.to_out[0].weight, self.pool.get(M, D), att.to_out[0].bias)
+        out = self.out_proj_ln(a, att.to_out[0], att.to_out[1].g, x)
         self.pool.put(a)
-        out = self.layernorm(o, att.to_out[1].g, self.pool.get(M, D), residual=x)
-        self.pool.put(o)
         return out
 
     def fullattn(self, blk, x):

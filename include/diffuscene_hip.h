@@ -87,6 +87,11 @@ int dsc_gemm_gn_silu_f32(const dsc_gemm_args* args, dsc_stream_t stream);
  * fixed order with bias / residual applied.  Restrictions: batch == 1, k2 == 0, act_out == DSC_ACT_NONE. */
 int dsc_gemm_splitk_f32(const dsc_gemm_args* a, int32_t splits, float* workspace, int64_t workspace_floats, dsc_stream_t stream);
 
+/* y = LayerNorm over the n = 512 output channels of ([a1 | a2] @ w^T + bias), times gamma, plus residual (optional): the
+ * out-projection + LayerNorm (+ residual) of LinearAttention (denoise_net.py:216-235 with :93-102; biased variance, eps from the
+ * struct, gain only).  Same argument struct as dsc_gemm_f32 (gamma = the LayerNorm gain, beta unused); one K row stride. */
+int dsc_gemm_layernorm_f32(const dsc_gemm_args* a, dsc_stream_t stream);
+
 /* Small-K linear for un-aligned inputs (first layer of _encoder_mlp on slices of the (B,N,C)
  * tensor, denoise_net.py:487,513-524; init_conv of the 5-channel re-arrangement model, :397):
  *   y[m][n] = act( sum_k x[m*ldx + k] * w[n*ldw + k] + bias[n] ),  k_in <= 64. */

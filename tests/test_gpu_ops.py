@@ -337,3 +337,26 @@ def test_splitk_gemm_and_grouped_colsum():
     for x, o in zip(mats, outs):
         ref = x.double().sum(0)
         assert float((o.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,res", [(20480, 128, True), (20000, 128, False), (100, 512, True)])
+def test_gemm_with_layernorm_epilogue(m, k, res):
+    """dsc_gemm_layernorm_f32: y = LayerNorm_channels(a @ W^T + b) * g (+ residual) (denoise_net.py:93-102 after :216-219) vs the
+    fp64 torch evaluation; 5e-6 relative to the output range."""
+    import ctypes as C
+    from diffuscene_amd import _lib, ops
+    torch.manual_seed(2)
+    a = torch.randn(m, k, device=dev())
+    w = torch.randn(512, k, device=dev()) / k ** 0.5
+    b = torch.randn(512, device=dev()) * 0.1
+    g = 1 + 0.1 * torch.randn(512, device=dev())
+    r = torch.randn(m, 512, device=dev()) if res else None
+    y = torch.empty(m, 512, device=dev())
+    args = ops.make_gemm_args(a, w, y, b, None, r, gamma=g, beta=g, eps=1e-5)
+    _lib.check(_lib.fn("dsc_gemm_layernorm_f32")(C.byref(args), ops.stream_ptr()), "dsc_gemm_layernorm_f32")
+    o = a.double() @ w.double().T + b.double()
+    mu = o.mean(1, keepdim=True)
+    var = o.var(1, unbiased=False, keepdim=True)
+    ref = (o - mu) * torch.rsqrt(var + 1e-5) * g.double() + (r.double() if res else 0)
+    assert float((y.double() - ref).abs().max() / ref.abs().max()) < 5e-6
