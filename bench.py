@@ -245,7 +245,7 @@ def roofline_dominant_kernel(plan, N, config_name):
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), measured by
-    # tools/profile_round.sh on the same workload -- bench.py cannot run the profiler on itself; the file records the git
+    # tools/gpu_round.sh (pmc step) + tools/pmc_summary.py on the same workload -- bench.py cannot run the profiler on itself; the file records the git
     # head it was measured at
     for tfile in ("profiles/r02_gemm_gn_hbm_traffic.json", "profiles/r01_gemm_gn_hbm_traffic.json"):
         path = os.path.join(ROOT, tfile)
