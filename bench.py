@@ -417,10 +417,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
-    import torch
-    import torch.distributed as dist
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DSC_BENCH_DRYRUN"):          # launcher plumbing only (CPU test): what each rank would run
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "world": ws, "gpus": args.gpus,
+                          "config": args.config, "scaling": args.scaling, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        if ws != args.gpus:
+            raise SystemExit(2)
+        return
+    import torch
+    import torch.distributed as dist
     if ws != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torchrun --nproc-per-node %d, or from a "
                          "plain shell so that bench.py spawns the ranks itself)" % (args.gpus, ws, args.gpus))

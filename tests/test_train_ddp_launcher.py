@@ -52,3 +52,21 @@ def test_launcher_shards_loader_and_redirects_rank_outputs(tmp_path):
         a, b = recs[0]["passes"][e], recs[1]["passes"][e]
         assert len(a) == len(b) == 11 and sorted(a + b) == list(range(22))   # disjoint shards that cover the dataset
     assert recs[0]["passes"][0] != recs[0]["passes"][1]               # a new permutation on every pass
+
+
+def test_bench_self_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` from a plain shell (how the driver calls it) re-executes itself under torch.distributed.run
+    with N ranks on 127.0.0.1; DSC_BENCH_DRYRUN stops every rank before it touches a GPU."""
+    env = dict(os.environ, DSC_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--scaling", "strong"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in recs] == [0, 1] and all(d["world"] == 2 and d["gpus"] == 2 for d in recs)
+    assert [d["local_rank"] for d in recs] == [0, 1] and all(d["master"] == "127.0.0.1" and d["scaling"] == "strong" for d in recs)
+    # under torchrun with a mismatching --gpus the script refuses instead of running a wrong configuration
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True,
+                        timeout=120)
+    assert r2.returncode != 0
