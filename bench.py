@@ -532,7 +532,7 @@ def main():
                 plan.x_in.normal_(); plan.t_in.fill_(500); plan.run()
         out["roofline"] = roofline_dominant_kernel(plan, N, args.config)
         log("roofline done")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and ws == 1:          # the CPU baseline is a single-GPU-run figure (rank 0, N = 1 only)
             out["cpu_baseline"] = cpu_baseline(spec, args.mode)
         print(json.dumps(out), flush=True)
     if ws > 1:
