@@ -202,19 +202,6 @@ class PointAffineFn(Function):
         return dx, dwp, dt, None, None, None
 
 
-class _ReluFn(Function):
-    @staticmethod
-    def forward(ctx, x):
-        y = torch.clamp_min(x, 0.0)
-        ctx.save_for_backward(y)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        y, = ctx.saved_tensors
-        return dy * (y > 0)
-
-
 # ------------------------------------------------------------------------------------------------ layers
 def _conv(x, conv):
     """nn.Conv1d(k=1) on token-major rows"""
@@ -313,8 +300,7 @@ class FoldingLayer(nn.Module):
                 x = _conv(x, m)
                 i += 1
             else:
-                x = _ReluFn.apply(x)
-                i += 1
+                raise NotImplementedError("FoldingLayer: an activation that does not follow a BatchNorm (not in the reference)")
         return x
 
 
