@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/diffuscene_hip.h"
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -52,6 +53,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// wave-wide sum on the DPP data path (VALU row shifts / broadcasts, no LDS crossbar round trips): the total lands in lane 63
+// and is broadcast with a readlane.  Same association order for every lane -> deterministic.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp_add = [](float x, auto ctrl, auto row_mask, auto bank_mask) {
+        const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value,
+                                                  decltype(bank_mask)::value, true);
+        return x + __builtin_bit_cast(float, y);
+    };
+    using std::integral_constant;
+    v = dpp_add(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:1
+    v = dpp_add(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:2
+    v = dpp_add(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:4
+    v = dpp_add(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{});   // row_shr:8
+    v = dpp_add(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{});   // row_bcast:15
+    v = dpp_add(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{});   // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

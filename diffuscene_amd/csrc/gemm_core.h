@@ -676,7 +676,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
                 const int tk = (j >= N ? j - N : j);
                 s += P[ct * BM + sc * N + tk];
             }
-            const float mu = wave_sum(s) * inv_cnt;
+            const float mu = wave_sum_dpp(s) * inv_cnt;
             float q = 0.f;
             for (int j = lane; j < 2 * N; j += 64) {
                 const int ct = 2 * g + (j >= N ? 1 : 0);
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
                 const float d = P[ct * BM + sc * N + tk] * (1.0f / 32.0f) - mu;
                 q += Q[ct * BM + sc * N + tk] + 32.0f * d * d;
             }
-            q = wave_sum(q);
+            q = wave_sum_dpp(q);
             if (lane == 0) stat[st] = f32x2{mu, 1.0f / sqrtf(q * inv_cnt + p.eps)};
         }
         __syncthreads();
