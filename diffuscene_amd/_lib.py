@@ -113,7 +113,6 @@ SIGNATURES = {
                                            C.c_int64, C.c_void_p]),
     "dsc_postfilter_compact_f32": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                              C.c_void_p, C.c_void_p]),
-    "dsc_stream_delay": (C.c_int, [C.c_int64, C.c_void_p]),
     "dsc_gemm_tn_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p,
                                   C.c_int64, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_gemm_tn_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -137,22 +137,6 @@ extern "C" int dsc_p_sample_f32(const float* x_t, const float* model_out, const 
     return 0;
 }
 
-// One wave that idles for `ns` nanoseconds of the 100 MHz constant clock (s_memrealtime): the phase offset between the
-// two half-batch chains of a captured step (sampler.py) -- a chain that starts half a GEMM late runs its MFMA main loops
-// under the other chain's epilogues for the rest of the step.
-__global__ void stream_delay_kernel(long long ticks) {
-    const unsigned long long s = __builtin_amdgcn_s_memrealtime();
-    while ((long long)(__builtin_amdgcn_s_memrealtime() - s) < ticks) __builtin_amdgcn_s_sleep(16);
-}
-
-extern "C" int dsc_stream_delay(int64_t ns, dsc_stream_t stream) {
-    if (ns < 0 || ns > 10000000) return DSC_ERANGE;
-    DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)(ns / 10));
-    DSC_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t stream) {
     if (!t || count < 1) return DSC_EINVAL;
     DSC_CLEAR_STALE_ERROR();

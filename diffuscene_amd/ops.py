@@ -251,11 +251,6 @@ def postfilter_compact(samples, empty_col, per_scene=False, keep_empty=False):
     return packed, counts
 
 
-def stream_delay(ns):
-    """Idle the current stream for ``ns`` nanoseconds (device-side, capturable)."""
-    _lib.check(_lib.fn("dsc_stream_delay")(int(ns), stream_ptr()), "dsc_stream_delay")
-
-
 def complete_overwrite(x, partial, noise, t, sqrt_ac, sqrt_1mac):
     _c(x, "x"); _c(partial, "partial"); _c(noise, "noise"); _dev(t, "t", torch.int64)
     b, n, c = x.shape

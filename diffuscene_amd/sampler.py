@@ -39,19 +39,14 @@ class NoiseReplay:
 
 def _chains_for(B):
     """Independent sub-batch chains per captured step (env DSC_CHAINS, default 1).  Scenes are independent, so the batch
-    can run as several dependency chains on separate streams inside the graph, optionally phase-shifted by
-    DSC_CHAIN_OFFSET_NS (a device-side delay at the head of the side chains).  Measured on MI355X (B=256, N=80,
-    tools/chain_sweep.py): with the round-1 GEMMs two 128-scene chains gained 3 % (12.07 vs 12.44 ms, offset 0; every
-    non-zero offset lost); with the interleaved LDS-DMA GEMMs one chain is best (10.73 ms vs 10.97 ms for two, 12.1 ms for
-    four) -- a single 256-scene chain already fills the CUs and leaves no launch gaps -- so it stays opt-in."""
+    can run as several dependency chains on separate streams inside the graph.  Measured on MI355X (B=256, N=80,
+    profiles/r02_chain_sweep_*.txt): with the round-1 GEMMs two 128-scene chains gained 3 % (12.07 vs 12.44 ms; starting the
+    second chain 15-110 us late so that its K loops run under the first chain's epilogues lost on every offset); with the
+    interleaved LDS-DMA GEMMs one chain is best (10.73 ms vs 10.97 ms for two, 12.1 ms for four) -- a single 256-scene chain
+    already fills the CUs and leaves no launch gaps -- so it stays opt-in (useful when the per-GPU batch is far above 256)."""
     import os
     n = int(os.environ.get("DSC_CHAINS", "1"))
     return n if (n > 1 and B % n == 0 and B // n >= 64) else 1
-
-
-def _chain_offset_ns():
-    import os
-    return int(os.environ.get("DSC_CHAIN_OFFSET_NS", "0"))
 
 
 class _StepGraph:
@@ -67,7 +62,6 @@ class _StepGraph:
                                   None if condition_cross is None else condition_cross[i * Bc:(i + 1) * Bc],
                                   time_table=use_table, slot=i) for i in range(nch)]
         self.plan = self.plans[0]
-        self.chain_offset_ns = _chain_offset_ns()
         self.side = [torch.cuda.Stream(device=device) for _ in range(nch - 1)]
         tb = diff.tables(device)
         ca, cb = diff._coeffs(tb)
@@ -111,8 +105,6 @@ class _StepGraph:
             run_chain(0)
             for i, st in enumerate(self.side):
                 with torch.cuda.stream(st):
-                    if self.chain_offset_ns > 0:
-                        ops.stream_delay(self.chain_offset_ns * (i + 1))
                     run_chain(i + 1)
             for st in self.side:
                 cur.wait_stream(st)

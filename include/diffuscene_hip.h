@@ -170,10 +170,6 @@ int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t st
 int dsc_postfilter_compact_f32(const float* samples, int32_t b, int32_t n, int32_t c, int32_t empty_col, int32_t mode,
                                int32_t keep_empty, float* packed, int32_t* counts, dsc_stream_t stream);
 
-/* Stream-ordered idle of `ns` nanoseconds (one wave on the constant 100 MHz clock; ns <= 10 ms).  No reference counterpart:
- * it sets the phase offset between the independent half-batch chains of one captured reverse step (sampler.py). */
-int dsc_stream_delay(int64_t ns, dsc_stream_t stream);
-
 /* Inpainting overwrite of p_sample_loop_complete (:462-466): rows [0,p) of every scene of x
  * (b, n, c) are replaced by q_sample(partial, t, noise) (partial/noise are (b, p, c)). */
 int dsc_complete_overwrite_f32(float* x, const float* partial, const float* noise, const int64_t* t,
