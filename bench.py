@@ -452,6 +452,7 @@ def main():
     if ws > 1:
         from diffuscene_amd import ddp
         ddp.broadcast_parameters(model)             # every replica starts from rank 0's weights
+        barrier(ws)                                 # no collective in flight while the sampling graph is being captured
     log("model on device")
     n_s = {"both": (args.steps + 1) // 2, "sample": args.steps, "train": 0}[args.mode]
     n_t = args.steps - n_s
