@@ -1,0 +1,371 @@
+// EXPERIMENT (not part of the product, not linked into libdiffuscene_hip.so): an f32-accurate GEMM on the bf16 matrix cores.
+//
+//   out[m][n] = bias[n] + sum_k x[m][k] * w[n][k]          x, w, out: f32 in HBM, as in dsc_gemm_f32
+//
+// Every f32 operand is split EXACTLY into three bf16 pieces (x = x1 + x2 + x3, round-to-nearest at each step, 8 + 8 + 8
+// mantissa bits), every bf16 x bf16 product is exact in f32, and the six products whose weight is >= 2^-18 of the leading
+// one are accumulated in f32 by v_mfma_f32_16x16x32_bf16:
+//
+//   x*w ~= x1*w1 + x1*w2 + x2*w1 + x2*w2 + x1*w3 + x3*w1       (dropped: x2*w3, x3*w2, x3*w3 <= 2^-26 relative)
+//
+// tools/gemm_bf16x6.py measures the error against an f64 product next to dsc_gemm_f32's (CPU emulation in
+// profiles/r02_bf16x6_numerics.txt: rms error 1.2e-7 vs 2.9e-7 for the f32 MFMA order of summation).  The bf16 pipe is 16x
+// the f32 MFMA rate, so six products are 2.67x the f32-MFMA roofline -- IF the operand split (11 VALU per pair of x
+// elements, done on the fragments after the LDS read) and the LDS traffic fit under the MFMAs.  That is what this measures.
+//
+// Layout: block 160 tokens x 256 channels (M = 20480, n = 512 -> 256 blocks = one round of 256 CUs), 8 waves as 2 x 4, wave
+// tile 80 x 64 = 5 x 4 MFMA blocks of 16 x 16, BK = 32 = one MFMA k-step.  x stays f32 in LDS (20 KiB / stage), the weights
+// are pre-split into three bf16 planes [3][n][k] by split_planes_kernel (once per weight update) and staged as planes
+// (48 KiB / stage); two stages, both filled by LDS-DMA (lane-linear image, XOR swizzles applied on the global side).
+// The MFMA computes out^T (weights as the row operand) so that each lane holds 4 consecutive channels of one token: the
+// plain epilogue is one 16-byte store per accumulator.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 160, BN = 256, BK = 32, NW = 8, T = NW * 64;
+constexpr int A_STAGE = BM * BK * 4;                    // 20480 B of f32 tokens
+constexpr int B_PLANE = BN * BK * 2;                    // 16384 B per bf16 weight plane
+constexpr int STAGE = A_STAGE + 3 * B_PLANE;            // 69632 B
+constexpr int CH_A = A_STAGE / 1024, CH_B = 3 * B_PLANE / 1024, CH = CH_A + CH_B;   // 20 + 48 one-KiB wave transfers
+constexpr int NI = (CH + NW - 1) / NW;                  // 9 per wave (the ragged round re-fetches chunks 0..3: same bytes)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));     // v_cvt_pk_bf16_f32, round to nearest even
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// exact 3-way split of 8 consecutive f32 into three packed bf16x8 fragments
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    u32x4 a, b, c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = q < 2 ? lo[2 * q] : hi[2 * q - 4], x1 = q < 2 ? lo[2 * q + 1] : hi[2 * q - 3];
+        const unsigned u1 = cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - bf_lo(u1), r1 = x1 - bf_hi(u1);
+        const unsigned u2 = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - bf_lo(u2), s1 = r1 - bf_hi(u2);
+        a[q] = u1;
+        b[q] = u2;
+        c[q] = cvt_pk_bf16(s0, s1);
+    }
+    p1 = __builtin_bit_cast(bf16x8, a);
+    p2 = __builtin_bit_cast(bf16x8, b);
+    p3 = __builtin_bit_cast(bf16x8, c);
+}
+
+__global__ void split_planes_kernel(const float* __restrict__ w, long count, uint16_t* __restrict__ planes) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= count) return;
+    const float x0 = w[i], x1 = i + 1 < count ? w[i + 1] : 0.f;
+    const unsigned u1 = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - bf_lo(u1), r1 = x1 - bf_hi(u1);
+    const unsigned u2 = cvt_pk_bf16(r0, r1);
+    const unsigned u3 = cvt_pk_bf16(r0 - bf_lo(u2), r1 - bf_hi(u2));
+    const unsigned u[3] = {u1, u2, u3};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        planes[p * count + i] = (uint16_t)(u[p] & 0xffffu);
+        if (i + 1 < count) planes[p * count + i + 1] = (uint16_t)(u[p] >> 16);
+    }
+}
+
+struct Args {
+    const float* x;          // [m][lda] f32
+    const uint16_t* planes;  // [3][n][k] bf16
+    const float* bias;       // [n] or null
+    float* out;              // [m][ldc]
+    int m, n, k, lda, ldc;
+};
+
+template <int PRODUCTS, int PIPE>
+__global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave_u & 1, wn = wave_u >> 1;
+    // XCD-aware block order: the two channel halves of a token block sit next to each other on one XCD (shared x rows in its L2)
+    const int cbs = p.n / BN, rbs = (p.m + BM - 1) / BM;
+    int rb, cb;
+    if ((rbs & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        rb = xcd * (rbs >> 3) + idx / cbs;
+        cb = idx % cbs;
+    } else {
+        rb = blockIdx.x / cbs;
+        cb = blockIdx.x % cbs;
+    }
+    const int row0 = rb * BM, col0 = cb * BN;
+    const int rows_here = min(BM, p.m - row0);
+    const float* const xb = p.x + (int64_t)row0 * p.lda;
+    const uint16_t* const wb = p.planes + (int64_t)col0 * p.k;
+    const int plane_bytes = p.n * p.k * 2;
+
+    int dvoff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int c = wave_u + NW * i;
+        if (c >= CH) c -= CH;
+        if (c < CH_A) {                                  // 8 token rows x 128 B; k-quad q lands in slot q ^ (row & 7)
+            const int r = c * 8 + (lane >> 3);
+            dvoff[i] = (r < rows_here ? r : 0) * p.lda * 4 + (((lane & 7) ^ (r & 7)) << 4);
+        } else {                                         // 16 channel rows x 64 B of one plane; k-octet g lands in slot g ^ ((n >> 1) & 3)
+            const int cbk = c - CH_A, plane = cbk >> 4, nrow = (cbk & 15) * 16 + (lane >> 2);
+            dvoff[i] = plane * plane_bytes + nrow * p.k * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4);
+        }
+    }
+    auto dma_tile = [&](int kt, char* stage) {
+        const int k0 = kt * BK;
+        __attribute__((address_space(3))) char* lbase = (__attribute__((address_space(3))) char*)stage;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int c = wave_u + NW * i;
+            if (c >= CH) c -= CH;
+            const bool isx = c < CH_A;                   // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                isx ? (void*)const_cast<float*>(xb) : (void*)const_cast<uint16_t*>(wb), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lbase + c * 1024, 16, dvoff[i], isx ? k0 * 4 : k0 * 2, 0, 0);
+#else
+            (void)isx; (void)k0; (void)lbase;
+#endif
+        }
+    };
+
+    // accumulators: out^T blocks, lane = (token lane&15, channels 4*(lane>>4) .. +3); bias folded into the initial value
+    f32x4 acc[5][4];
+    const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b4 = *(const f32x4*)(p.bias + col0 + wn * 64 + j * 16 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i][j] = b4;
+    }
+
+    // per-lane LDS byte offsets of the fragments inside a stage
+    int aoff[5][2], woff[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = wm * 80 + i * 16 + l15;
+        aoff[i][0] = r * 128 + (((2 * g) ^ (r & 7)) << 4);
+        aoff[i][1] = r * 128 + (((2 * g + 1) ^ (r & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nr = wn * 64 + j * 16 + l15;
+        woff[j] = A_STAGE + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4);
+    }
+
+    const int KT = p.k / BK;
+    auto mma_block = [&](const bf16x8 (&wf)[4][3], const bf16x8& x1, const bf16x8& x2, const bf16x8& x3, f32x4 (&c)[4]) {
+        // product-major: the same accumulator comes round every 4th MFMA (64 cycles apart); small terms first
+        if (PRODUCTS >= 6) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], x1, c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], x3, c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], x2, c[j], 0, 0, 0);
+        }
+        if (PRODUCTS >= 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], x1, c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], x2, c[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], x1, c[j], 0, 0, 0);
+    };
+    constexpr int NMMA = 4 * PRODUCTS;                   // MFMAs per 16-token block
+    dma_tile(0, smem);
+    if constexpr (PIPE == 0) {
+        // compiler-scheduled: split and MFMA stretches alternate; the SIMD's other wave is what fills the gaps
+        for (int kt = 0; kt < KT; ++kt) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this wave's chunks of tile kt are in LDS
+            __syncthreads();                             // everyone's are, and nobody still reads the other stage
+            if (kt + 1 < KT) dma_tile(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+            const char* st = smem + (kt & 1) * STAGE;
+            bf16x8 wf[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(st + woff[j] + pl * B_PLANE);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const f32x4 lo = *(const f32x4*)(st + aoff[i][0]), hi = *(const f32x4*)(st + aoff[i][1]);
+                bf16x8 x1, x2, x3;
+                split8(lo, hi, x1, x2, x3);
+                mma_block(wf, x1, x2, x3, acc[i]);
+            }
+        }
+    } else if constexpr (PIPE == 1) {
+        // PIPE 1: inside a K tile the split of token block i+1 (44 VALU) is slotted between the MFMAs of block i, and the
+        // f32 fragment of block i+2 is read under them; only block 0's split and the weight-plane reads are exposed per tile.
+        for (int kt = 0; kt < KT; ++kt) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            if (kt + 1 < KT) dma_tile(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+            const char* st = smem + (kt & 1) * STAGE;
+            bf16x8 wf[4][3];
+            f32x4 raw[2][2];
+            bf16x8 xs[2][3];
+            raw[0][0] = *(const f32x4*)(st + aoff[0][0]);
+            raw[0][1] = *(const f32x4*)(st + aoff[0][1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(st + woff[j] + pl * B_PLANE);
+            raw[1][0] = *(const f32x4*)(st + aoff[1][0]);
+            raw[1][1] = *(const f32x4*)(st + aoff[1][1]);
+            split8(raw[0][0], raw[0][1], xs[0][0], xs[0][1], xs[0][2]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i + 2 < 5) {
+                    raw[i & 1][0] = *(const f32x4*)(st + aoff[i + 2][0]);
+                    raw[i & 1][1] = *(const f32x4*)(st + aoff[i + 2][1]);
+                }
+                if (i + 1 < 5)
+                    split8(raw[(i + 1) & 1][0], raw[(i + 1) & 1][1], xs[(i + 1) & 1][0], xs[(i + 1) & 1][1], xs[(i + 1) & 1][2]);
+                mma_block(wf, xs[i & 1][0], xs[i & 1][1], xs[i & 1][2], acc[i]);
+                if (i + 1 < 5) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i + 2 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                    for (int q = 0; q < NMMA - 2; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2), 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // PIPE 2: the pipeline runs ACROSS K tiles.  Block s = 5*kt + i: its MFMAs use the split made under block s-1's MFMAs
+        // from the f32 fragment read under block s-2's.  Tile kt+1 is confirmed (vmcnt(0) + barrier) at the start of block 3
+        // of tile kt: by then every fragment of tile kt is in registers, so the same barrier frees stage kt&1 for the DMA
+        // of tile kt+2, and blocks 3/4 read tile kt+1's first token fragments and its weight planes (second register set).
+        // No exposed split or LDS latency per tile; the tail issues harmless duplicate DMAs / reads instead of branching.
+        bf16x8 wfA[4][3], wfB[4][3];
+        f32x4 raw[2][2];
+        bf16x8 xs[2][3];
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        dma_tile(KT > 1 ? 1 : 0, smem + STAGE);
+        raw[0][0] = *(const f32x4*)(smem + aoff[0][0]);
+        raw[0][1] = *(const f32x4*)(smem + aoff[0][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wfA[j][pl] = *(const bf16x8*)(smem + woff[j] + pl * B_PLANE);
+        raw[1][0] = *(const f32x4*)(smem + aoff[1][0]);
+        raw[1][1] = *(const f32x4*)(smem + aoff[1][1]);
+        split8(raw[0][0], raw[0][1], xs[0][0], xs[0][1], xs[0][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        auto tile = [&](auto par_c, int kt, const bf16x8 (&wfc)[4][3], bf16x8 (&wfn)[4][3]) {
+            constexpr int PAR = decltype(par_c)::value;          // kt & 1 == PAR; block parity of block i is (PAR + i) & 1
+            const char* cur = smem + PAR * STAGE;
+            const char* nxt = smem + (PAR ^ 1) * STAGE;
+            auto block = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int sp = (PAR + i) & 1;
+                if constexpr (i == 3) {
+                    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): tile kt+1 landed, my reads of tile kt done
+                    __syncthreads();
+                    dma_tile(min(kt + 2, KT - 1), const_cast<char*>(cur));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const char* src = i + 2 < 5 ? cur : nxt;
+                constexpr int blk = i + 2 < 5 ? i + 2 : i + 2 - 5;
+                raw[sp][0] = *(const f32x4*)(src + aoff[blk][0]);
+                raw[sp][1] = *(const f32x4*)(src + aoff[blk][1]);
+                if constexpr (i >= 3) {
+#pragma unroll
+                    for (int j = 2 * (i - 3); j < 2 * (i - 3) + 2; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) wfn[j][pl] = *(const bf16x8*)(nxt + woff[j] + pl * B_PLANE);
+                }
+                split8(raw[sp ^ 1][0], raw[sp ^ 1][1], xs[sp ^ 1][0], xs[sp ^ 1][1], xs[sp ^ 1][2]);
+                mma_block(wfc, xs[sp][0], xs[sp][1], xs[sp][2], acc[i]);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if constexpr (i >= 3) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NMMA - 2 - (i >= 3 ? 3 : 0); ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2) + (i >= 3 ? 1 : 0), 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            block(std::integral_constant<int, 0>{});
+            block(std::integral_constant<int, 1>{});
+            block(std::integral_constant<int, 2>{});
+            block(std::integral_constant<int, 3>{});
+            block(std::integral_constant<int, 4>{});
+        };
+        for (int kt = 0; kt < KT; kt += 2) {                     // KT is even (host checks k % 64 == 0)
+            tile(std::integral_constant<int, 0>{}, kt, wfA, wfB);
+            tile(std::integral_constant<int, 1>{}, kt + 1, wfB, wfA);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+
+    float* const ob = p.out + (int64_t)row0 * p.ldc + col0 + wn * 64 + 4 * g;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = wm * 80 + i * 16 + l15;
+        if (r < rows_here) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = acc[i][j];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bf16x6_split_planes(const float* w, long count, uint16_t* planes, hipStream_t s) {
+    const long pairs = (count + 1) / 2;
+    split_planes_kernel<<<(unsigned)((pairs + 255) / 256), 256, 0, s>>>(w, count, planes);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// products: 6 = f32-accurate, 3 = "bf16x3" (about 2^-17), 1 = plain bf16 (the pipe's ceiling with the same data movement)
+int bf16x6_gemm(const float* x, int lda, const uint16_t* planes, const float* bias, float* out, int ldc, int m, int n, int k,
+                int products, int pipe, hipStream_t s) {
+    if (n % BN || k % BK || (lda & 3) || (ldc & 3) || m <= 0) return 2;
+    if ((int64_t)BM * lda * 4 >= 0x7fffffffLL || 3LL * n * k * 2 >= 0x7fffffffLL) return 3;   // 32-bit DMA offsets
+    Args a{x, planes, bias, out, m, n, k, lda, ldc};
+    const unsigned grid = (unsigned)(((m + BM - 1) / BM) * (n / BN));
+    if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 2 && k % 64 == 0) gemm_bf16_split_kernel<6, 2><<<grid, T, 0, s>>>(a);
+    else if (products == 3 && pipe == 2 && k % 64 == 0) gemm_bf16_split_kernel<3, 2><<<grid, T, 0, s>>>(a);
+    else if (products == 3 && pipe == 0) gemm_bf16_split_kernel<3, 0><<<grid, T, 0, s>>>(a);
+    else if (products == 3 && pipe == 1) gemm_bf16_split_kernel<3, 1><<<grid, T, 0, s>>>(a);
+    else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0><<<grid, T, 0, s>>>(a);
+    else return 2;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+}  // extern "C"

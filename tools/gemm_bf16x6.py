@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""EXPERIMENT harness for tools/gemm_bf16x6.hip (f32-accurate GEMM on the bf16 matrix cores; not part of the product).
+
+    python tools/gemm_bf16x6.py --build            # build container: hipcc -> tools/libgemm_bf16x6.so (travels to the GPU box)
+    python tools/gemm_bf16x6.py [--k 512,1024]     # GPU box: error vs an f64 product and order-unbiased timing
+
+For every K: the error of each variant and of the product's dsc_gemm_f32 against torch's f64 matmul (max / rms, relative to
+the rms of the result), an identity check with an asymmetric weight (catches operand / row-column swaps), and round-robin
+timing after a clock warm-up (same method as tools/gemm_ab.py).  TF figures are ALGORITHMIC f32 flops (2*M*N*K)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SO = os.path.join(ROOT, "tools", "libgemm_bf16x6.so")
+
+
+def build():
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           os.path.join(ROOT, "tools", "gemm_bf16x6.hip"), "-o", SO])
+    print("built", SO)
+
+
+def opt(name, default):
+    for i, a in enumerate(sys.argv):
+        if a == name:
+            return sys.argv[i + 1]
+    return default
+
+
+def main():
+    if "--build" in sys.argv:
+        return build()
+    import numpy as np
+    import torch
+    from diffuscene_amd import ops
+
+    lib = C.CDLL(SO)
+    lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    lib.bf16x6_gemm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_void_p]
+    dev = torch.device("cuda:0")
+    B, N = int(opt("--batch", "256")), int(opt("--objects", "80"))
+    M, NOUT = B * N, int(opt("--n", "512"))
+    variants = [(6, 0), (6, 1), (6, 2), (3, 2), (1, 0)]          # (products, pipeline)
+    torch.manual_seed(0)
+    for K in [int(x) for x in opt("--k", "512,1024").split(",")]:
+        x = torch.nn.functional.silu(torch.randn(M, K, device=dev)) * 1.3
+        w = torch.randn(NOUT, K, device=dev) / K ** 0.5
+        b = torch.randn(NOUT, device=dev) * 0.1
+        planes = torch.empty(3, NOUT, K, device=dev, dtype=torch.int16)
+        s = ops.stream_ptr()
+
+        def split(wt):
+            assert lib.bf16x6_split_planes(wt.data_ptr(), wt.numel(), planes.data_ptr(), s) == 0
+
+        def run(v, out, xin=x, bias=b):
+            rc = lib.bf16x6_gemm(xin.data_ptr(), xin.stride(0), planes.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 out.data_ptr(), out.stride(0), M, NOUT, K, v[0], v[1], s)
+            assert rc == 0, (v, rc)
+
+        # 1. plane split is exact: w1 + w2 + w3 == w bit for bit
+        split(w)
+        pf = (planes.to(torch.int32) << 16).view(torch.float32)
+        exact = bool(torch.equal(pf[0] + pf[1] + pf[2], w))
+        print("K=%d  plane split exact: %s" % (K, exact), flush=True)
+
+        # 2. identity check with an asymmetric operand: x = [I | 0] rows, out[m][n] must equal w[n][m % K] (+ bias)
+        eye = torch.zeros(M, K, device=dev)
+        eye[torch.arange(M, device=dev), torch.arange(M, device=dev) % K] = 1.0
+        want = w.t()[torch.arange(M, device=dev) % K] + b
+        for v in variants[:3]:
+            out = torch.zeros(M, NOUT, device=dev)
+            run(v, out, eye)
+            torch.cuda.synchronize()
+            print("K=%d  identity check products=%d pipe=%d: max |diff| = %.3e" % (K, v[0], v[1], float((out - want).abs().max())),
+                  flush=True)
+
+        # 3. error against f64
+        ref = x.double() @ w.double().t() + b.double()
+        rms = float(ref.pow(2).mean().sqrt())
+
+        def err(y):
+            d = (y.double() - ref).abs()
+            return float(d.max()) / rms, float(d.pow(2).mean().sqrt()) / rms
+
+        y_prod = ops.gemm(x, w, b)
+        torch.cuda.synchronize()
+        print("K=%d  dsc_gemm_f32 (f32 MFMA)        max %.2e  rms %.2e" % ((K,) + err(y_prod)), flush=True)
+        print("K=%d  torch f32 matmul               max %.2e  rms %.2e" % ((K,) + err(x @ w.t() + b)), flush=True)
+        outs = {}
+        for v in variants:
+            outs[v] = torch.zeros(M, NOUT, device=dev)
+            run(v, outs[v])
+            torch.cuda.synchronize()
+            print("K=%d  bf16 split products=%d pipe=%d   max %.2e  rms %.2e" % ((K, v[0], v[1]) + err(outs[v])), flush=True)
+
+        # 4. timing, round-robin after a clock warm-up; "prod" = the product kernel on the same operands
+        yp = torch.empty(M, NOUT, device=dev)
+        gp = ops.make_gemm_args(x, w, yp, b)
+        names = ["prod"] + variants
+
+        def launch(v):
+            if v == "prod":
+                ops.run_gemm(gp)
+            else:
+                run(v, outs[v])
+
+        for _ in range(150):
+            launch("prod")
+        times = {v: [] for v in names}
+        for rnd in range(9):
+            order = names[rnd % len(names):] + names[:rnd % len(names)]
+            evs = []
+            for v in order:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    launch(v)
+                e1.record()
+                evs.append((v, e0, e1))
+            torch.cuda.synchronize()
+            for v, e0, e1 in evs:
+                times[v].append(e0.elapsed_time(e1) * 100.0)
+        flops = 2.0 * M * NOUT * K
+        for v in names:
+            us = float(np.median(times[v]))
+            label = "dsc_gemm_f32" if v == "prod" else "bf16 split products=%d pipe=%d" % v
+            extra = "" if v == "prod" else "  bf16 pipe: %.0f TF = %.3f of 2500" % (flops * v[0] / us / 1e6, flops * v[0] / us / 1e6 / 2500)
+            print("K=%4d  %-34s %7.1f us [%6.1f..%6.1f]  %6.1f TF f32-equivalent (%.3f of the f32-MFMA peak)%s" % (
+                K, label, us, min(times[v]), max(times[v]), flops / us / 1e6, flops / us / 1e6 / 157.3, extra), flush=True)
+
+
+if __name__ == "__main__":
+    main()
