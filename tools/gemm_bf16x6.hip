@@ -86,9 +86,13 @@ struct Args {
     const float* bias;       // [n] or null
     float* out;              // [m][ldc]
     int m, n, k, lda, ldc;
+    // GroupNorm(8 groups of 64 channels over the 80 tokens of a scene) + (scale + 1, shift) + SiLU (+ residual) epilogue
+    const float* gamma; const float* beta; float eps;
+    const float* scale_shift; int ld_ss;   // per scene: [scale(n) | shift(n)], or null
+    const float* residual; int ldr;        // or null
 };
 
-template <int PRODUCTS, int PIPE>
+template <int PRODUCTS, int PIPE, bool GN = false>
 __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,12 +334,81 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);
 
     float* const ob = p.out + (int64_t)row0 * p.ldc + col0 + wn * 64 + 4 * g;
+    if constexpr (!GN) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int r = wm * 80 + i * 16 + l15;
-        if (r < rows_here) {
+        for (int i = 0; i < 5; ++i) {
+            const int r = wm * 80 + i * 16 + l15;
+            if (r < rows_here) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = acc[i][j];
+                for (int j = 0; j < 4; ++j) *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = acc[i][j];
+            }
+        }
+    } else {
+        // The wave tile IS one GroupNorm cell: 80 tokens of scene (row0 / 80 + wm) x the 64 channels of group (col0 / 64 + wn).
+        // Statistics are wave-local (two passes over the 80 accumulators of a lane + a wave sum): no LDS, no block barrier.
+        const int cbase = col0 + wn * 64 + 4 * g;
+        const int scene = row0 / 80 + wm;
+        f32x4 ga[4], be[4], sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                    // issued first: their latency hides under the statistics
+            ga[j] = *(const f32x4*)(p.gamma + cbase + j * 16);
+            be[j] = *(const f32x4*)(p.beta + cbase + j * 16);
+            if (p.scale_shift) {
+                const float* ssr = p.scale_shift + (int64_t)min(scene, p.m / 80 - 1) * p.ld_ss + cbase + j * 16;
+                sc[j] = *(const f32x4*)ssr;
+                sh[j] = *(const f32x4*)(ssr + p.n);
+            } else {
+                sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sh[j] = sc[j];
+            }
+        }
+        auto wave_sum = [](float v) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            return v;
+        };
+        float s0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0 += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        const float mean = wave_sum(s0) * (1.f / 5120.f);
+        float q0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[i][j][e] - mean;
+                    q0 = fmaf(d, d, q0);
+                }
+        const float rstd = 1.f / sqrtf(wave_sum(q0) * (1.f / 5120.f) + p.eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                // y = z * A + B with A = rstd*gamma*(scale+1), B = (beta - mean*rstd*gamma)*(scale+1) + shift
+                const float a = rstd * ga[j][e], sp1 = sc[j][e] + 1.f;
+                ga[j][e] = a * sp1;
+                be[j][e] = fmaf(be[j][e] - mean * a, sp1, sh[j][e]);
+            }
+        const float* const rbp = p.residual ? p.residual + (int64_t)row0 * p.ldr + cbase : nullptr;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int r = wm * 80 + i * 16 + l15;
+            if (r < rows_here) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaf(acc[i][j][e], ga[j][e], be[j][e]);
+                        y[e] = t / (1.f + __expf(-t));
+                    }
+                    if (rbp) y += *(const f32x4*)(rbp + (int64_t)r * p.ldr + j * 16);
+                    *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = y;
+                }
+            }
         }
     }
 }
@@ -355,7 +428,7 @@ int bf16x6_gemm(const float* x, int lda, const uint16_t* planes, const float* bi
                 int products, int pipe, hipStream_t s) {
     if (n % BN || k % BK || (lda & 3) || (ldc & 3) || m <= 0) return 2;
     if ((int64_t)BM * lda * 4 >= 0x7fffffffLL || 3LL * n * k * 2 >= 0x7fffffffLL) return 3;   // 32-bit DMA offsets
-    Args a{x, planes, bias, out, m, n, k, lda, ldc};
+    Args a{x, planes, bias, out, m, n, k, lda, ldc, nullptr, nullptr, 0.f, nullptr, 0, nullptr, 0};
     const unsigned grid = (unsigned)(((m + BM - 1) / BM) * (n / BN));
     if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0><<<grid, T, 0, s>>>(a);
     else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1><<<grid, T, 0, s>>>(a);
@@ -364,6 +437,21 @@ int bf16x6_gemm(const float* x, int lda, const uint16_t* planes, const float* bi
     else if (products == 3 && pipe == 0) gemm_bf16_split_kernel<3, 0><<<grid, T, 0, s>>>(a);
     else if (products == 3 && pipe == 1) gemm_bf16_split_kernel<3, 1><<<grid, T, 0, s>>>(a);
     else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0><<<grid, T, 0, s>>>(a);
+    else return 2;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// Block.forward as one launch for scenes of exactly 80 tokens: SiLU(GroupNorm8(x.w^T + bias) * (scale + 1) + shift) (+ residual);
+// scale_shift rows are per scene ([scale(n) | shift(n)], DSC_SS_PER_SCENE), or null.  Six products, pipe 1 or 2.
+int bf16x6_gemm_gn_silu(const float* x, int lda, const uint16_t* planes, const float* bias, const float* gamma, const float* beta,
+                        float eps, const float* scale_shift, int ld_ss, const float* residual, int ldr, float* out, int ldc,
+                        int m, int n, int k, int pipe, hipStream_t s) {
+    if (n % BN || k % BK || (lda & 3) || (ldc & 3) || (ldr & 3) || (ld_ss & 3) || m <= 0 || m % 80 || !gamma || !beta) return 2;
+    if ((int64_t)BM * lda * 4 >= 0x7fffffffLL || 3LL * n * k * 2 >= 0x7fffffffLL) return 3;
+    Args a{x, planes, bias, out, m, n, k, lda, ldc, gamma, beta, eps, scale_shift, ld_ss, residual, ldr};
+    const unsigned grid = (unsigned)(((m + BM - 1) / BM) * (n / BN));
+    if (pipe == 1) gemm_bf16_split_kernel<6, 1, true><<<grid, T, 0, s>>>(a);
+    else if (pipe == 2 && k % 64 == 0) gemm_bf16_split_kernel<6, 2, true><<<grid, T, 0, s>>>(a);
     else return 2;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }

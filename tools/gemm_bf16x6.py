@@ -41,6 +41,9 @@ def main():
     lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     lib.bf16x6_gemm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]
+    lib.bf16x6_gemm_gn_silu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]
     dev = torch.device("cuda:0")
     B, N = int(opt("--batch", "256")), int(opt("--objects", "80"))
     M, NOUT = B * N, int(opt("--n", "512"))
@@ -131,6 +134,67 @@ def main():
             extra = "" if v == "prod" else "  bf16 pipe: %.0f TF = %.3f of 2500" % (flops * v[0] / us / 1e6, flops * v[0] / us / 1e6 / 2500)
             print("K=%4d  %-34s %7.1f us [%6.1f..%6.1f]  %6.1f TF f32-equivalent (%.3f of the f32-MFMA peak)%s" % (
                 K, label, us, min(times[v]), max(times[v]), flops / us / 1e6, flops / us / 1e6 / 157.3, extra), flush=True)
+
+
+        # 5. the fused Block epilogue (wave-local GroupNorm): error vs an f64 evaluation next to dsc_gemm_gn_silu_f32, and timing
+        if N == 80:
+            gamma, beta = torch.rand(NOUT, device=dev) + 0.5, torch.randn(NOUT, device=dev) * 0.1
+            ss = torch.randn(B, 2 * NOUT, device=dev) * 0.1
+            res = torch.randn(M, NOUT, device=dev)
+            z = ref.view(B, N, NOUT // 64, 64)
+            mu = z.mean(dim=(1, 3), keepdim=True)
+            var = z.var(dim=(1, 3), unbiased=False, keepdim=True)
+            zn = ((z - mu) / (var + 1e-5).sqrt()).view(B, N, NOUT) * gamma.double() + beta.double()
+            zn = zn * (ss[:, None, :NOUT].double() + 1) + ss[:, None, NOUT:].double()
+            ref_gn = (zn * torch.sigmoid(zn)).view(M, NOUT) + res.double()
+            rms_gn = float(ref_gn.pow(2).mean().sqrt())
+
+            def err_gn(y):
+                d = (y.double() - ref_gn).abs()
+                return float(d.max()) / rms_gn, float(d.pow(2).mean().sqrt()) / rms_gn
+
+            yp = torch.empty(M, NOUT, device=dev)
+            ggn = ops.make_gemm_args(x, w, yp, b, None, res, gamma=gamma, beta=beta, tokens_per_scene=N, scale_shift=ss, ss_mode=2)
+            ops.run_gemm(ggn, gn=True)
+            torch.cuda.synchronize()
+            print("K=%d  GN  dsc_gemm_gn_silu_f32          max %.2e  rms %.2e" % ((K,) + err_gn(yp)), flush=True)
+            ygn = {pp: torch.zeros(M, NOUT, device=dev) for pp in (1, 2)}
+
+            def run_gn(pp):
+                rc = lib.bf16x6_gemm_gn_silu(x.data_ptr(), x.stride(0), planes.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             1e-5, ss.data_ptr(), ss.stride(0), res.data_ptr(), res.stride(0), ygn[pp].data_ptr(),
+                                             ygn[pp].stride(0), M, NOUT, K, pp, s)
+                assert rc == 0, rc
+
+            for pp in (1, 2):
+                run_gn(pp)
+                torch.cuda.synchronize()
+                print("K=%d  GN  bf16 split x6 pipe=%d          max %.2e  rms %.2e" % ((K, pp) + err_gn(ygn[pp])), flush=True)
+            names = ["prod", 1, 2]
+            for _ in range(150):
+                ops.run_gemm(ggn, gn=True)
+            times = {v: [] for v in names}
+            for rnd in range(9):
+                order = names[rnd % 3:] + names[:rnd % 3]
+                evs = []
+                for v in order:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        if v == "prod":
+                            ops.run_gemm(ggn, gn=True)
+                        else:
+                            run_gn(v)
+                    e1.record()
+                    evs.append((v, e0, e1))
+                torch.cuda.synchronize()
+                for v, e0, e1 in evs:
+                    times[v].append(e0.elapsed_time(e1) * 100.0)
+            for v in names:
+                us = float(np.median(times[v]))
+                print("K=%4d  GN  %-30s %7.1f us [%6.1f..%6.1f]  %6.1f TF f32-equivalent (%.3f of the f32-MFMA peak)" % (
+                    K, "dsc_gemm_gn_silu_f32" if v == "prod" else "bf16 split x6 pipe=%d" % v, us, min(times[v]), max(times[v]),
+                    flops / us / 1e6, flops / us / 1e6 / 157.3), flush=True)
 
 
 if __name__ == "__main__":
