@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""CPU check of the index arithmetic of tools/gemm_bf16x6.hip (written without a GPU at hand): the LDS-DMA image with its
+global-side XOR swizzles, the per-lane fragment offsets, the 16x16x32 MFMA operand / result lane maps and the store addresses are
+re-stated here with the SAME integer expressions and run on a small problem in numpy.  It proves the pieces are consistent with
+each other and with out = x . w^T (it cannot prove the hardware lane maps, which are taken from the CDNA4 guide; the GPU harness'
+identity check does that).     python tools/gemm_bf16x6_indexcheck.py"""
+import numpy as np
+
+BM, BN, BK, NW = 160, 256, 32, 8
+A_STAGE, B_PLANE = BM * BK * 4, BN * BK * 2
+CH_A, CH_B = A_STAGE // 1024, 3 * B_PLANE // 1024
+CH = CH_A + CH_B
+NI = (CH + NW - 1) // NW
+
+
+def main():
+    rng = np.random.default_rng(0)
+    M, N, K = 2 * BM, 2 * BN, 64
+    lda = K + 8                                             # a row stride that is not K
+    x = rng.standard_normal((M, lda)).astype(np.float32)
+    # "planes": any three distinct matrices stand in for the bf16 pieces (kept as f32 values here; 2-byte elements in the byte image)
+    planes = rng.integers(-50, 50, size=(3, N, K)).astype(np.int16)
+    xbytes = x.view(np.uint8).reshape(-1)
+    pbytes = planes.view(np.uint8).reshape(-1)
+    out = np.zeros((M, N), np.float64)
+    rbs, cbs = M // BM, N // BN
+    for blk in range(rbs * cbs):
+        rb, cb = blk // cbs, blk % cbs                      # (the XCD remap only permutes blocks)
+        row0, col0 = rb * BM, cb * BN
+        xb = row0 * lda * 4                                 # byte offset of the block's first token row
+        wb = col0 * K * 2                                   # byte offset of the block's first channel row in plane 0
+        plane_bytes = N * K * 2
+        acc = np.zeros((NW, 5, 4, 64, 4), np.float64)
+        for kt in range(K // BK):
+            k0 = kt * BK
+            lds = np.zeros(A_STAGE + 3 * B_PLANE, np.uint8)
+            for wave in range(NW):
+                for i in range(NI):
+                    c = wave + NW * i
+                    if c >= CH:
+                        c -= CH
+                    for lane in range(64):
+                        if c < CH_A:
+                            r = c * 8 + (lane >> 3)
+                            voff = r * lda * 4 + (((lane & 7) ^ (r & 7)) << 4)
+                            src = xbytes[xb + voff + k0 * 4: xb + voff + k0 * 4 + 16]
+                        else:
+                            cbk = c - CH_A
+                            plane, nrow = cbk >> 4, (cbk & 15) * 16 + (lane >> 2)
+                            voff = plane * plane_bytes + nrow * K * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4)
+                            src = pbytes[wb + voff + k0 * 2: wb + voff + k0 * 2 + 16]
+                        lds[c * 1024 + lane * 16: c * 1024 + lane * 16 + 16] = src
+            for wave in range(NW):
+                wm, wn = wave & 1, wave >> 1
+                for lane in range(64):
+                    g, l15 = lane >> 4, lane & 15
+                    wf = np.zeros((4, 3, 8), np.float64)
+                    for j in range(4):
+                        nr = wn * 64 + j * 16 + l15
+                        woff = A_STAGE + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4)
+                        for pl in range(3):
+                            wf[j, pl] = lds[woff + pl * B_PLANE: woff + pl * B_PLANE + 16].view(np.int16)
+                    acc_lane_w = wf
+                    for i in range(5):
+                        r = wm * 80 + i * 16 + l15
+                        a0 = r * 128 + (((2 * g) ^ (r & 7)) << 4)
+                        a1 = r * 128 + (((2 * g + 1) ^ (r & 7)) << 4)
+                        xf = np.concatenate([lds[a0:a0 + 16].view(np.float32), lds[a1:a1 + 16].view(np.float32)]).astype(np.float64)
+                        # stash the fragments; the MFMA is evaluated below over all lanes of the wave
+                        FR.setdefault((wave, i), np.zeros((64, 8)))[lane] = xf
+                    FW[wave, lane] = acc_lane_w
+            # MFMA 16x16x32: D[row][col] += sum_k A[row][k] B[k][col]; lane l holds A[l&15][8*(l>>4)+e], B[8*(l>>4)+e][l&15];
+            # result lane l, reg e: row 4*(l>>4)+e, col l&15.  A = weight fragment (plane sum stands for the six products), B = tokens.
+            for wave in range(NW):
+                for i in range(5):
+                    for j in range(4):
+                        Amat = np.zeros((16, 32))
+                        Bmat = np.zeros((32, 16))
+                        for lane in range(64):
+                            g, l15 = lane >> 4, lane & 15
+                            Amat[l15, 8 * g: 8 * g + 8] = FW[wave, lane][j].sum(axis=0)     # w1 + w2 + w3
+                            Bmat[8 * g: 8 * g + 8, l15] = FR[(wave, i)][lane]
+                        D = Amat @ Bmat
+                        for lane in range(64):
+                            g, l15 = lane >> 4, lane & 15
+                            acc[wave, i, j, lane] += D[4 * g: 4 * g + 4, l15]
+        for wave in range(NW):
+            wm, wn = wave & 1, wave >> 1
+            for lane in range(64):
+                g, l15 = lane >> 4, lane & 15
+                for i in range(5):
+                    r = wm * 80 + i * 16 + l15
+                    for j in range(4):
+                        n = col0 + wn * 64 + 4 * g + j * 16
+                        out[row0 + r, n: n + 4] = acc[wave, i, j, lane]
+    ref = x[:, :K].astype(np.float64) @ planes.astype(np.float64).sum(axis=0).T
+    err = np.abs(out - ref).max()
+    print("max |emulated kernel - x.w^T| = %.3e over %d x %d outputs (K = %d, 2 x 2 blocks)" % (err, M, N, K))
+    assert err < 1e-9 * max(1.0, np.abs(ref).max())
+    print("index arithmetic consistent")
+
+
+def bank_check():
+    """ds_read_b128: the LDS serves 128 B per clock = 8 lanes x 16 B; conflict-free when each run of 8 consecutive lanes touches
+    8 distinct 16-byte bank groups ((address / 16) mod 8)."""
+    worst = 1
+    for wave in range(NW):
+        wm, wn = wave & 1, wave >> 1
+        for i in range(5):
+            for half in range(2):
+                ad = []
+                for lane in range(64):
+                    g, l15 = lane >> 4, lane & 15
+                    r = wm * 80 + i * 16 + l15
+                    ad.append(r * 128 + (((2 * g + half) ^ (r & 7)) << 4))
+                for q in range(8):
+                    grp = [(a >> 4) & 7 for a in ad[8 * q: 8 * q + 8]]
+                    worst = max(worst, max(grp.count(v) for v in grp))
+        for j in range(4):
+            ad = []
+            for lane in range(64):
+                g, l15 = lane >> 4, lane & 15
+                nr = wn * 64 + j * 16 + l15
+                ad.append(A_STAGE + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4))
+            for q in range(8):
+                grp = [(a >> 4) & 7 for a in ad[8 * q: 8 * q + 8]]
+                worst = max(worst, max(grp.count(v) for v in grp))
+    print("fragment reads: worst bank-group multiplicity within 8 consecutive lanes = %d (1 = conflict-free)" % worst)
+    assert worst == 1
+
+
+FR, FW = {}, {}
+if __name__ == "__main__":
+    main()
+    bank_check()
