@@ -2,7 +2,7 @@
 """EXPERIMENT harness for tools/gemm_bf16x6.hip (f32-accurate GEMM on the bf16 matrix cores; not part of the product).
 
     python tools/gemm_bf16x6.py --build            # build container: hipcc -> tools/libgemm_bf16x6.so (travels to the GPU box)
-    python tools/gemm_bf16x6.py [--k 512,1024]     # GPU box: error vs an f64 product and order-unbiased timing
+    python tools/gemm_bf16x6.py [--k 512,1024] [--noslp]   # GPU box: error vs an f64 product and order-unbiased timing
 
 For every K: the error of each variant and of the product's dsc_gemm_f32 against torch's f64 matmul (max / rms, relative to
 the rms of the result), an identity check with an asymmetric weight (catches operand / row-column swaps), and round-robin
@@ -15,12 +15,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SO = os.path.join(ROOT, "tools", "libgemm_bf16x6.so")
+SO_NOSLP = os.path.join(ROOT, "tools", "libgemm_bf16x6_noslp.so")   # scalar f32 subtractions in the split instead of v_pk_add_f32
 
 
 def build():
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           os.path.join(ROOT, "tools", "gemm_bf16x6.hip"), "-o", SO])
-    print("built", SO)
+    for so, extra in ((SO, []), (SO_NOSLP, ["-fno-slp-vectorize"])):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra +
+                              [os.path.join(ROOT, "tools", "gemm_bf16x6.hip"), "-o", so])
+        print("built", so)
 
 
 def opt(name, default):
@@ -37,7 +39,8 @@ def main():
     import torch
     from diffuscene_amd import ops
 
-    lib = C.CDLL(SO)
+    lib = C.CDLL(SO_NOSLP if "--noslp" in sys.argv else SO)
+    print("library:", "no-SLP build (scalar subtractions)" if "--noslp" in sys.argv else "default build (v_pk_add_f32 in the split)")
     lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     lib.bf16x6_gemm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_void_p]
