@@ -31,12 +31,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 160, BN = 256, BK = 32, NW = 8, T = NW * 64;
-constexpr int A_STAGE = BM * BK * 4;                    // 20480 B of f32 tokens
-constexpr int B_PLANE = BN * BK * 2;                    // 16384 B per bf16 weight plane
-constexpr int STAGE = A_STAGE + 3 * B_PLANE;            // 69632 B
-constexpr int CH_A = A_STAGE / 1024, CH_B = 3 * B_PLANE / 1024, CH = CH_A + CH_B;   // 20 + 48 one-KiB wave transfers
-constexpr int NI = (CH + NW - 1) / NW;                  // 9 per wave (the ragged round re-fetches chunks 0..3: same bytes)
+constexpr int BK = 32, NW = 8, T = NW * 64;
+// A block is WM x WN waves of 80 tokens x 64 channels (8 waves): 2 x 4 -> 160 x 256 (one round at M = 20480, n = 512),
+// 4 x 2 -> 320 x 128 (n = 384 / 128 and other multiples of 128).
+template <int WM, int WN>
+struct Cfg {
+    static_assert(WM * WN == NW, "8 waves");
+    static constexpr int BM = 80 * WM, BN = 64 * WN;
+    static constexpr int A_STAGE = BM * BK * 4;                  // f32 tokens
+    static constexpr int B_PLANE = BN * BK * 2;                  // one bf16 weight plane
+    static constexpr int STAGE = A_STAGE + 3 * B_PLANE;
+    static constexpr int CH_A = A_STAGE / 1024, CH_PL = B_PLANE / 1024, CH = CH_A + 3 * CH_PL;   // one-KiB wave transfers
+    static constexpr int NI = (CH + NW - 1) / NW;                // per wave (a ragged last round re-fetches chunks 0..: same bytes)
+};
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     f32x2v v = {a, b};
@@ -81,7 +88,9 @@ __global__ void split_planes_kernel(const float* __restrict__ w, long count, uin
 }
 
 struct Args {
-    const float* x;          // [m][lda] f32
+    const float* x;          // [m][lda] f32: the first k1 columns of the K range
+    const float* x2;         // [m][lda] f32: columns k1 .. k (torch.cat of a skip connection), or null when k1 == k
+    int k1;
     const uint16_t* planes;  // [3][n][k] bf16
     const float* bias;       // [n] or null
     float* out;              // [m][ldc]
@@ -89,15 +98,19 @@ struct Args {
     // GroupNorm(8 groups of 64 channels over the 80 tokens of a scene) + (scale + 1, shift) + SiLU (+ residual) epilogue
     const float* gamma; const float* beta; float eps;
     const float* scale_shift; int ld_ss;   // per scene: [scale(n) | shift(n)], or null
-    const float* residual; int ldr;        // or null
+    const float* residual; int ldr;        // or null (added after the activation)
+    int act;                               // plain epilogue: 0 none, 1 GELU (erf), 2 SiLU
 };
 
-template <int PRODUCTS, int PIPE, bool GN = false>
+template <int PRODUCTS, int PIPE, bool GN = false, int WM = 2, int WN = 4>
 __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
+    using C = Cfg<WM, WN>;
+    constexpr int BM = C::BM, BN = C::BN, A_STAGE = C::A_STAGE, B_PLANE = C::B_PLANE, STAGE = C::STAGE, CH_A = C::CH_A,
+                  CH_PL = C::CH_PL, CH = C::CH, NI = C::NI;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave_u & 1, wn = wave_u >> 1;
+    const int wm = wave_u % WM, wn = wave_u / WM;
     // XCD-aware block order: the two channel halves of a token block sit next to each other on one XCD (shared x rows in its L2)
     const int cbs = p.n / BN, rbs = (p.m + BM - 1) / BM;
     int rb, cb;
@@ -112,6 +125,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     const int row0 = rb * BM, col0 = cb * BN;
     const int rows_here = min(BM, p.m - row0);
     const float* const xb = p.x + (int64_t)row0 * p.lda;
+    const float* const xb2 = p.x2 ? p.x2 + (int64_t)row0 * p.lda : xb;
     const uint16_t* const wb = p.planes + (int64_t)col0 * p.k;
     const int plane_bytes = p.n * p.k * 2;
 
@@ -124,12 +138,15 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             const int r = c * 8 + (lane >> 3);
             dvoff[i] = (r < rows_here ? r : 0) * p.lda * 4 + (((lane & 7) ^ (r & 7)) << 4);
         } else {                                         // 16 channel rows x 64 B of one plane; k-octet g lands in slot g ^ ((n >> 1) & 3)
-            const int cbk = c - CH_A, plane = cbk >> 4, nrow = (cbk & 15) * 16 + (lane >> 2);
+            const int cbk = c - CH_A, plane = cbk / CH_PL, nrow = (cbk % CH_PL) * 16 + (lane >> 2);
             dvoff[i] = plane * plane_bytes + nrow * p.k * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4);
         }
     }
     auto dma_tile = [&](int kt, char* stage) {
         const int k0 = kt * BK;
+        const bool seg1 = k0 < p.k1;
+        const float* const xs_ = seg1 ? xb : xb2;
+        const int sx = (seg1 ? k0 : k0 - p.k1) * 4;
         __attribute__((address_space(3))) char* lbase = (__attribute__((address_space(3))) char*)stage;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -138,10 +155,10 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             const bool isx = c < CH_A;                   // wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                isx ? (void*)const_cast<float*>(xb) : (void*)const_cast<uint16_t*>(wb), 0, 0x7fffffff, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lbase + c * 1024, 16, dvoff[i], isx ? k0 * 4 : k0 * 2, 0, 0);
+                isx ? (void*)const_cast<float*>(xs_) : (void*)const_cast<uint16_t*>(wb), 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lbase + c * 1024, 16, dvoff[i], isx ? sx : k0 * 2, 0, 0);
 #else
-            (void)isx; (void)k0; (void)lbase;
+            (void)isx; (void)sx; (void)xs_; (void)lbase;
 #endif
         }
     };
@@ -335,12 +352,24 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 
     float* const ob = p.out + (int64_t)row0 * p.ldc + col0 + wn * 64 + 4 * g;
     if constexpr (!GN) {
+        const float* const rbp = p.residual ? p.residual + (int64_t)row0 * p.ldr + col0 + wn * 64 + 4 * g : nullptr;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int r = wm * 80 + i * 16 + l15;
             if (r < rows_here) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = acc[i][j];
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 y = acc[i][j];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = 0.5f * y[e] * (1.f + erff(y[e] * 0.70710678118654752f));
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.f + __expf(-y[e]));
+                    }
+                    if (rbp) y += *(const f32x4*)(rbp + (int64_t)r * p.ldr + j * 16);
+                    *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = y;
+                }
             }
         }
     } else {
@@ -415,6 +444,29 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 
 }  // namespace
 
+// One launcher for every variant.  gn: fused Block epilogue (scenes of exactly 80 tokens).  products: 6 = f32-accurate,
+// 3 = "bf16x3" (about 2^-17), 1 = plain bf16 (the pipe's ceiling with the same data movement).  pipe: 0 compiler-scheduled,
+// 1 split pipelined inside a K tile, 2 across K tiles.  tile: 0 = 160 x 256 when n % 256 == 0 else 320 x 128; 1 / 2 force one.
+template <int WM, int WN>
+static int launch_cfg(const Args& a, int gn, int products, int pipe, hipStream_t s) {
+    using C = Cfg<WM, WN>;
+    if (a.n % C::BN) return 2;
+    if ((int64_t)C::BM * a.lda * 4 >= 0x7fffffffLL || 3LL * a.n * a.k * 2 >= 0x7fffffffLL) return 3;   // 32-bit DMA offsets
+    const unsigned grid = (unsigned)(((a.m + C::BM - 1) / C::BM) * (a.n / C::BN));
+    if (gn) {
+        if (products != 6) return 2;
+        if (pipe == 1) gemm_bf16_split_kernel<6, 1, true, WM, WN><<<grid, T, 0, s>>>(a);
+        else if (pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, true, WM, WN><<<grid, T, 0, s>>>(a);
+        else return 2;
+    } else if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0, false, WM, WN><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1, false, WM, WN><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, false, WM, WN><<<grid, T, 0, s>>>(a);
+    else if (products == 3 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<3, 2, false, WM, WN><<<grid, T, 0, s>>>(a);
+    else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0, false, WM, WN><<<grid, T, 0, s>>>(a);
+    else return 2;
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 extern "C" {
 
 int bf16x6_split_planes(const float* w, long count, uint16_t* planes, hipStream_t s) {
@@ -423,37 +475,15 @@ int bf16x6_split_planes(const float* w, long count, uint16_t* planes, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// products: 6 = f32-accurate, 3 = "bf16x3" (about 2^-17), 1 = plain bf16 (the pipe's ceiling with the same data movement)
-int bf16x6_gemm(const float* x, int lda, const uint16_t* planes, const float* bias, float* out, int ldc, int m, int n, int k,
-                int products, int pipe, hipStream_t s) {
-    if (n % BN || k % BK || (lda & 3) || (ldc & 3) || m <= 0) return 2;
-    if ((int64_t)BM * lda * 4 >= 0x7fffffffLL || 3LL * n * k * 2 >= 0x7fffffffLL) return 3;   // 32-bit DMA offsets
-    Args a{x, planes, bias, out, m, n, k, lda, ldc, nullptr, nullptr, 0.f, nullptr, 0, nullptr, 0};
-    const unsigned grid = (unsigned)(((m + BM - 1) / BM) * (n / BN));
-    if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0><<<grid, T, 0, s>>>(a);
-    else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1><<<grid, T, 0, s>>>(a);
-    else if (products == 6 && pipe == 2 && k % 64 == 0) gemm_bf16_split_kernel<6, 2><<<grid, T, 0, s>>>(a);
-    else if (products == 3 && pipe == 2 && k % 64 == 0) gemm_bf16_split_kernel<3, 2><<<grid, T, 0, s>>>(a);
-    else if (products == 3 && pipe == 0) gemm_bf16_split_kernel<3, 0><<<grid, T, 0, s>>>(a);
-    else if (products == 3 && pipe == 1) gemm_bf16_split_kernel<3, 1><<<grid, T, 0, s>>>(a);
-    else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0><<<grid, T, 0, s>>>(a);
-    else return 2;
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-
-// Block.forward as one launch for scenes of exactly 80 tokens: SiLU(GroupNorm8(x.w^T + bias) * (scale + 1) + shift) (+ residual);
-// scale_shift rows are per scene ([scale(n) | shift(n)], DSC_SS_PER_SCENE), or null.  Six products, pipe 1 or 2.
-int bf16x6_gemm_gn_silu(const float* x, int lda, const uint16_t* planes, const float* bias, const float* gamma, const float* beta,
-                        float eps, const float* scale_shift, int ld_ss, const float* residual, int ldr, float* out, int ldc,
-                        int m, int n, int k, int pipe, hipStream_t s) {
-    if (n % BN || k % BK || (lda & 3) || (ldc & 3) || (ldr & 3) || (ld_ss & 3) || m <= 0 || m % 80 || !gamma || !beta) return 2;
-    if ((int64_t)BM * lda * 4 >= 0x7fffffffLL || 3LL * n * k * 2 >= 0x7fffffffLL) return 3;
-    Args a{x, planes, bias, out, m, n, k, lda, ldc, gamma, beta, eps, scale_shift, ld_ss, residual, ldr};
-    const unsigned grid = (unsigned)(((m + BM - 1) / BM) * (n / BN));
-    if (pipe == 1) gemm_bf16_split_kernel<6, 1, true><<<grid, T, 0, s>>>(a);
-    else if (pipe == 2 && k % 64 == 0) gemm_bf16_split_kernel<6, 2, true><<<grid, T, 0, s>>>(a);
-    else return 2;
-    return hipGetLastError() == hipSuccess ? 0 : 1;
+int bf16x6_launch(const float* x, const float* x2, int k1, int lda, const uint16_t* planes, const float* bias, float* out, int ldc,
+                  int m, int n, int k, int act, const float* residual, int ldr, int gn, const float* gamma, const float* beta,
+                  float eps, const float* scale_shift, int ld_ss, int products, int pipe, int tile, hipStream_t s) {
+    if (k % BK || k1 % BK || k1 <= 0 || k1 > k || (k1 < k && !x2) || (lda & 3) || (ldc & 3) || (ldr & 3) || (ld_ss & 3) || m <= 0)
+        return 2;
+    if (gn && (m % 80 || !gamma || !beta)) return 2;
+    Args a{x, k1 < k ? x2 : nullptr, k1, planes, bias, out, m, n, k, lda, ldc, gamma, beta, eps, scale_shift, ld_ss, residual, ldr, act};
+    if (tile == 1 || (tile == 0 && n % 256 == 0)) return launch_cfg<2, 4>(a, gn, products, pipe, s);
+    return launch_cfg<4, 2>(a, gn, products, pipe, s);
 }
 
 }  // extern "C"

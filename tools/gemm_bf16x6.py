@@ -42,11 +42,22 @@ def main():
     lib = C.CDLL(SO_NOSLP if "--noslp" in sys.argv else SO)
     print("library:", "no-SLP build (scalar subtractions)" if "--noslp" in sys.argv else "default build (v_pk_add_f32 in the split)")
     lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
-    lib.bf16x6_gemm.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                C.c_int, C.c_int, C.c_void_p]
-    lib.bf16x6_gemm_gn_silu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
-                                        C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p]
+    lib.bf16x6_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,   # x x2 k1 lda planes bias out ldc
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,                                # m n k act residual ldr
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,                        # gn gamma beta eps ss ld_ss
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]                                                  # products pipe tile stream
+
+    def ptr(t):
+        return t.data_ptr() if t is not None else None
+
+    def launch6(xin, planes_t, bias, out, m, n, k, products, pipe, x2=None, k1=None, act=0, residual=None, gn=None, tile=0, stream=None):
+        gamma, beta, ss = gn if gn is not None else (None, None, None)
+        rc = lib.bf16x6_launch(ptr(xin), ptr(x2), k if k1 is None else k1, xin.stride(0), ptr(planes_t), ptr(bias), ptr(out), out.stride(0),
+                               m, n, k, act, ptr(residual), residual.stride(0) if residual is not None else 0,
+                               1 if gn is not None else 0, ptr(gamma), ptr(beta), 1e-5, ptr(ss), ss.stride(0) if ss is not None else 0,
+                               products, pipe, tile, stream)
+        assert rc == 0, ("bf16x6_launch", rc, products, pipe)
+
     dev = torch.device("cuda:0")
     B, N = int(opt("--batch", "256")), int(opt("--objects", "80"))
     M, NOUT = B * N, int(opt("--n", "512"))
@@ -63,9 +74,7 @@ def main():
             assert lib.bf16x6_split_planes(wt.data_ptr(), wt.numel(), planes.data_ptr(), s) == 0
 
         def run(v, out, xin=x, bias=b):
-            rc = lib.bf16x6_gemm(xin.data_ptr(), xin.stride(0), planes.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                 out.data_ptr(), out.stride(0), M, NOUT, K, v[0], v[1], s)
-            assert rc == 0, (v, rc)
+            launch6(xin, planes, bias, out, M, NOUT, K, v[0], v[1], stream=s)
 
         # 1. plane split is exact: w1 + w2 + w3 == w bit for bit
         split(w)
@@ -164,10 +173,7 @@ def main():
             ygn = {pp: torch.zeros(M, NOUT, device=dev) for pp in (1, 2)}
 
             def run_gn(pp):
-                rc = lib.bf16x6_gemm_gn_silu(x.data_ptr(), x.stride(0), planes.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                             1e-5, ss.data_ptr(), ss.stride(0), res.data_ptr(), res.stride(0), ygn[pp].data_ptr(),
-                                             ygn[pp].stride(0), M, NOUT, K, pp, s)
-                assert rc == 0, rc
+                launch6(x, planes, b, ygn[pp], M, NOUT, K, 6, pp, residual=res, gn=(gamma, beta, ss), stream=s)
 
             for pp in (1, 2):
                 run_gn(pp)
@@ -198,6 +204,50 @@ def main():
                 print("K=%4d  GN  %-30s %7.1f us [%6.1f..%6.1f]  %6.1f TF f32-equivalent (%.3f of the f32-MFMA peak)" % (
                     K, "dsc_gemm_gn_silu_f32" if v == "prod" else "bf16 split x6 pipe=%d" % v, us, min(times[v]), max(times[v]),
                     flops / us / 1e6, flops / us / 1e6 / 157.3), flush=True)
+
+
+        # 6. the other forms the product needs: two K segments (torch.cat of a skip connection), GELU + residual epilogue, and the
+        #    320 x 128 tile for n = 384 -- each against dsc_gemm_f32 on the same operands
+        if K >= 128:
+            h = K // 2
+            xa, xb_ = x[:, :h].contiguous(), x[:, h:].contiguous()
+            y2 = torch.zeros(M, NOUT, device=dev)
+            launch6(xa, planes, b, y2, M, NOUT, K, 6, 2 if K % 64 == 0 else 1, x2=xb_, k1=h, stream=s)
+            torch.cuda.synchronize()
+            print("K=%d  two segments (%d+%d)           max %.2e  rms %.2e" % ((K, h, h) + err(y2)), flush=True)
+        res2 = torch.randn(M, NOUT, device=dev)
+        y3 = torch.zeros(M, NOUT, device=dev)
+        launch6(x, planes, b, y3, M, NOUT, K, 6, 2, act=1, residual=res2, stream=s)
+        yp3 = ops.gemm(x, w, b, residual=res2, act_out=1)
+        torch.cuda.synchronize()
+        print("K=%d  GELU + residual vs dsc_gemm_f32: max |diff| / rms = %.2e" % (K, float((y3 - yp3).abs().max()) / float(yp3.pow(2).mean().sqrt())),
+              flush=True)
+        n3 = 384
+        w3 = torch.randn(n3, K, device=dev) / K ** 0.5
+        planes3 = torch.empty(3, n3, K, device=dev, dtype=torch.int16)
+        assert lib.bf16x6_split_planes(w3.data_ptr(), w3.numel(), planes3.data_ptr(), s) == 0
+        y4 = torch.zeros(M, n3, device=dev)
+        ref3 = x.double() @ w3.double().t()
+        for pp in (1, 2):
+            launch6(x, planes3, None, y4, M, n3, K, 6, pp, stream=s)
+            torch.cuda.synchronize()
+            d = (y4.double() - ref3).abs()
+            print("K=%d  n=384 (320x128 tile) pipe=%d      max %.2e  rms %.2e" % (K, pp, float(d.max()) / float(ref3.pow(2).mean().sqrt()),
+                                                                                float(d.pow(2).mean().sqrt()) / float(ref3.pow(2).mean().sqrt())), flush=True)
+        yp4 = torch.empty(M, n3, device=dev)
+        g4 = ops.make_gemm_args(x, w3, yp4, None)
+        tt = {}
+        for name, fn in (("dsc_gemm_f32", lambda: ops.run_gemm(g4)), ("bf16 split x6 pipe=2", lambda: launch6(x, planes3, None, y4, M, n3, K, 6, 2, stream=s))):
+            for _ in range(30):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            tt[name] = e0.elapsed_time(e1) * 1000.0 / 30
+            print("K=%4d  n=384  %-24s %7.1f us  %6.1f TF f32-equivalent" % (K, name, tt[name], 2.0 * M * n3 * K / tt[name] / 1e6), flush=True)
 
 
 if __name__ == "__main__":

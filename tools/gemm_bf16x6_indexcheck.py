@@ -6,18 +6,23 @@ each other and with out = x . w^T (it cannot prove the hardware lane maps, which
 identity check does that).     python tools/gemm_bf16x6_indexcheck.py"""
 import numpy as np
 
-BM, BN, BK, NW = 160, 256, 32, 8
-A_STAGE, B_PLANE = BM * BK * 4, BN * BK * 2
-CH_A, CH_B = A_STAGE // 1024, 3 * B_PLANE // 1024
-CH = CH_A + CH_B
-NI = (CH + NW - 1) // NW
+BK, NW = 32, 8
 
 
-def main():
+def main(WM, WN):
+    global BM, BN, A_STAGE, B_PLANE
+    FR.clear(); FW.clear()
+    BM, BN = 80 * WM, 64 * WN
+    A_STAGE, B_PLANE = BM * BK * 4, BN * BK * 2
+    CH_A, CH_PL = A_STAGE // 1024, B_PLANE // 1024
+    CH = CH_A + 3 * CH_PL
+    NI = (CH + NW - 1) // NW
     rng = np.random.default_rng(0)
-    M, N, K = 2 * BM, 2 * BN, 64
-    lda = K + 8                                             # a row stride that is not K
+    M, N, K, K1 = 2 * BM, 2 * BN, 96, 64                    # two K segments: 64 columns from x, 32 from x2
+    lda = 64 + 8                                            # a row stride that is not K (the same for both segments)
     x = rng.standard_normal((M, lda)).astype(np.float32)
+    x2 = rng.standard_normal((M, lda)).astype(np.float32)
+    x2bytes = x2.view(np.uint8).reshape(-1)
     # "planes": any three distinct matrices stand in for the bf16 pieces (kept as f32 values here; 2-byte elements in the byte image)
     planes = rng.integers(-50, 50, size=(3, N, K)).astype(np.int16)
     xbytes = x.view(np.uint8).reshape(-1)
@@ -43,15 +48,17 @@ def main():
                         if c < CH_A:
                             r = c * 8 + (lane >> 3)
                             voff = r * lda * 4 + (((lane & 7) ^ (r & 7)) << 4)
-                            src = xbytes[xb + voff + k0 * 4: xb + voff + k0 * 4 + 16]
+                            seg1 = k0 < K1
+                            sb, sx = (xbytes, k0 * 4) if seg1 else (x2bytes, (k0 - K1) * 4)
+                            src = sb[xb + voff + sx: xb + voff + sx + 16]
                         else:
                             cbk = c - CH_A
-                            plane, nrow = cbk >> 4, (cbk & 15) * 16 + (lane >> 2)
+                            plane, nrow = cbk // CH_PL, (cbk % CH_PL) * 16 + (lane >> 2)
                             voff = plane * plane_bytes + nrow * K * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4)
                             src = pbytes[wb + voff + k0 * 2: wb + voff + k0 * 2 + 16]
                         lds[c * 1024 + lane * 16: c * 1024 + lane * 16 + 16] = src
             for wave in range(NW):
-                wm, wn = wave & 1, wave >> 1
+                wm, wn = wave % WM, wave // WM
                 for lane in range(64):
                     g, l15 = lane >> 4, lane & 15
                     wf = np.zeros((4, 3, 8), np.float64)
@@ -85,7 +92,7 @@ def main():
                             g, l15 = lane >> 4, lane & 15
                             acc[wave, i, j, lane] += D[4 * g: 4 * g + 4, l15]
         for wave in range(NW):
-            wm, wn = wave & 1, wave >> 1
+            wm, wn = wave % WM, wave // WM
             for lane in range(64):
                 g, l15 = lane >> 4, lane & 15
                 for i in range(5):
@@ -93,19 +100,22 @@ def main():
                     for j in range(4):
                         n = col0 + wn * 64 + 4 * g + j * 16
                         out[row0 + r, n: n + 4] = acc[wave, i, j, lane]
-    ref = x[:, :K].astype(np.float64) @ planes.astype(np.float64).sum(axis=0).T
+    xcat = np.concatenate([x[:, :K1], x2[:, :K - K1]], axis=1)
+    ref = xcat.astype(np.float64) @ planes.astype(np.float64).sum(axis=0).T
     err = np.abs(out - ref).max()
-    print("max |emulated kernel - x.w^T| = %.3e over %d x %d outputs (K = %d, 2 x 2 blocks)" % (err, M, N, K))
+    print("tile %d x %d: max |emulated kernel - [x | x2].w^T| = %.3e over %d x %d outputs (K = %d + %d, 2 x 2 blocks)" % (
+        BM, BN, err, M, N, K1, K - K1))
     assert err < 1e-9 * max(1.0, np.abs(ref).max())
     print("index arithmetic consistent")
 
 
-def bank_check():
+def bank_check(WM, WN):
     """ds_read_b128: the LDS serves 128 B per clock = 8 lanes x 16 B; conflict-free when each run of 8 consecutive lanes touches
     8 distinct 16-byte bank groups ((address / 16) mod 8)."""
     worst = 1
+    A_STAGE = 80 * WM * BK * 4
     for wave in range(NW):
-        wm, wn = wave & 1, wave >> 1
+        wm, wn = wave % WM, wave // WM
         for i in range(5):
             for half in range(2):
                 ad = []
@@ -125,11 +135,12 @@ def bank_check():
             for q in range(8):
                 grp = [(a >> 4) & 7 for a in ad[8 * q: 8 * q + 8]]
                 worst = max(worst, max(grp.count(v) for v in grp))
-    print("fragment reads: worst bank-group multiplicity within 8 consecutive lanes = %d (1 = conflict-free)" % worst)
+    print("tile %d x %d fragment reads: worst bank-group multiplicity within 8 consecutive lanes = %d (1 = conflict-free)" % (80 * WM, 64 * WN, worst))
     assert worst == 1
 
 
 FR, FW = {}, {}
 if __name__ == "__main__":
-    main()
-    bank_check()
+    for cfg in ((2, 4), (4, 2)):
+        main(*cfg)
+        bank_check(*cfg)
