@@ -7,10 +7,10 @@ import torch
 torch.manual_seed(0)
 
 
-def split(x, n):
+def split(x, n, dt=torch.bfloat16):
     parts, r = [], x.clone()
     for _ in range(n):
-        p = r.bfloat16().float()
+        p = r.to(dt).float()
         parts.append(p)
         r = r - p
     return parts
@@ -41,6 +41,12 @@ def main():
             for (i, j) in sorted(terms, key=lambda t: -(t[0] + t[1])):      # small terms first, as the kernel does
                 y = y + a[i] @ w[j]
             print("  %-38s " % name, err(y))
+        # f16 pieces (11-bit mantissas: two pieces = 22 bits) need only three products but are range-bound: the second piece of a
+        # small operand is an f16 subnormal, so the error depends on the operands' scale -- not pursued
+        for scale in (1.0, 1e-3):
+            a, w = split(A * scale, 2, torch.float16), split(W, 2, torch.float16)
+            y = (a[0] @ w[1] + a[1] @ w[0] + a[0] @ w[0]) / scale
+            print("  %-38s " % ("f16 x3, activations scaled by %g" % scale), err(y))
 
 
 if __name__ == "__main__":
