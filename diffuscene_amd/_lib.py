@@ -8,6 +8,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiffuscene_hip.so")
+# DSC_HIP_LIB selects another build of the SAME library (e.g. the host-ASAN build of `python __graft_entry__.py --asan`);
+# it is still the HIP extension -- there is no fallback of any kind behind this switch.
+if os.environ.get("DSC_HIP_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["DSC_HIP_LIB"])
 
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_LEAKY01 = 0, 1, 2, 3
 SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
