@@ -13,8 +13,10 @@
 // the f32 MFMA rate, so six products are 2.67x the f32-MFMA roofline -- IF the operand split (11 VALU per pair of x
 // elements, done on the fragments after the LDS read) and the LDS traffic fit under the MFMAs.  That is what this measures.
 //
-// Layout: block 160 tokens x 256 channels (M = 20480, n = 512 -> 256 blocks = one round of 256 CUs), 8 waves as 2 x 4, wave
-// tile 80 x 64 = 5 x 4 MFMA blocks of 16 x 16, BK = 32 = one MFMA k-step.  x stays f32 in LDS (20 KiB / stage), the weights
+// Layout: 8 waves as WM x WN; a wave owns ONE scene (ntok <= 16*RB tokens, padded to RB MFMA row blocks inside LDS) x 64
+// channels = RB x 4 MFMA blocks of 16 x 16 -- exactly one GroupNorm cell.  RB = 5: 80-token scenes, block 160 tokens x 256
+// channels (M = 20480, n = 512 -> 256 blocks = one round of 256 CUs) or 320 x 128; RB = 2: scenes of <= 32 tokens (N = 21:
+// 4 scenes x 128 channels per block -> 256 blocks at B = 256).  Plain GEMMs use ntok = 16*RB (dense).  BK = 32 = one MFMA k-step.  x stays f32 in LDS (20 KiB / stage), the weights
 // are pre-split into three bf16 planes [3][n][k] by split_planes_kernel (once per weight update) and staged as planes
 // (48 KiB / stage); two stages, both filled by LDS-DMA (lane-linear image, XOR swizzles applied on the global side).
 // The MFMA computes out^T (weights as the row operand) so that each lane holds 4 consecutive channels of one token: the
@@ -34,10 +36,10 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int BK = 32, NW = 8, T = NW * 64;
 // A block is WM x WN waves of 80 tokens x 64 channels (8 waves): 2 x 4 -> 160 x 256 (one round at M = 20480, n = 512),
 // 4 x 2 -> 320 x 128 (n = 384 / 128 and other multiples of 128).
-template <int WM, int WN>
+template <int WM, int WN, int RB>
 struct Cfg {
     static_assert(WM * WN == NW, "8 waves");
-    static constexpr int BM = 80 * WM, BN = 64 * WN;
+    static constexpr int BM = 16 * RB * WM, BN = 64 * WN;        // BM = LDS rows (scenes padded to 16*RB); global rows = WM * ntok
     static constexpr int A_STAGE = BM * BK * 4;                  // f32 tokens
     static constexpr int B_PLANE = BN * BK * 2;                  // one bf16 weight plane
     static constexpr int STAGE = A_STAGE + 3 * B_PLANE;
@@ -95,16 +97,18 @@ struct Args {
     const float* bias;       // [n] or null
     float* out;              // [m][ldc]
     int m, n, k, lda, ldc;
-    // GroupNorm(8 groups of 64 channels over the 80 tokens of a scene) + (scale + 1, shift) + SiLU (+ residual) epilogue
+    int ntok;                // tokens per scene (<= 16*RB); dense GEMM: 16*RB
+    // GroupNorm(8 groups of 64 channels over the ntok tokens of a scene) + (scale + 1, shift) + SiLU (+ residual) epilogue
     const float* gamma; const float* beta; float eps;
     const float* scale_shift; int ld_ss;   // per scene: [scale(n) | shift(n)], or null
     const float* residual; int ldr;        // or null (added after the activation)
     int act;                               // plain epilogue: 0 none, 1 GELU (erf), 2 SiLU
 };
 
-template <int PRODUCTS, int PIPE, bool GN = false, int WM = 2, int WN = 4>
+template <int PRODUCTS, int PIPE, bool GN = false, int WM = 2, int WN = 4, int RB = 5>
 __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
-    using C = Cfg<WM, WN>;
+    static_assert(PIPE != 2 || RB >= 2, "the cross-tile pipeline reads two blocks ahead: one-block scenes would need a third stage");
+    using C = Cfg<WM, WN, RB>;
     constexpr int BM = C::BM, BN = C::BN, A_STAGE = C::A_STAGE, B_PLANE = C::B_PLANE, STAGE = C::STAGE, CH_A = C::CH_A,
                   CH_PL = C::CH_PL, CH = C::CH, NI = C::NI;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -112,7 +116,8 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave_u % WM, wn = wave_u / WM;
     // XCD-aware block order: the two channel halves of a token block sit next to each other on one XCD (shared x rows in its L2)
-    const int cbs = p.n / BN, rbs = (p.m + BM - 1) / BM;
+    const int scenes = (p.m + p.ntok - 1) / p.ntok;
+    const int cbs = p.n / BN, rbs = (scenes + WM - 1) / WM;
     int rb, cb;
     if ((rbs & 7) == 0) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -122,8 +127,8 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
         rb = blockIdx.x / cbs;
         cb = blockIdx.x % cbs;
     }
-    const int row0 = rb * BM, col0 = cb * BN;
-    const int rows_here = min(BM, p.m - row0);
+    const int row0 = rb * WM * p.ntok, col0 = cb * BN;          // first global token row of the block
+    const int rows_here = p.m - row0;                            // valid global rows from row0 on (may exceed the block)
     const float* const xb = p.x + (int64_t)row0 * p.lda;
     const float* const xb2 = p.x2 ? p.x2 + (int64_t)row0 * p.lda : xb;
     const uint16_t* const wb = p.planes + (int64_t)col0 * p.k;
@@ -134,9 +139,10 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     for (int i = 0; i < NI; ++i) {
         int c = wave_u + NW * i;
         if (c >= CH) c -= CH;
-        if (c < CH_A) {                                  // 8 token rows x 128 B; k-quad q lands in slot q ^ (row & 7)
-            const int r = c * 8 + (lane >> 3);
-            dvoff[i] = (r < rows_here ? r : 0) * p.lda * 4 + (((lane & 7) ^ (r & 7)) << 4);
+        if (c < CH_A) {                                  // 8 LDS rows x 128 B; k-quad q lands in slot q ^ (row & 7)
+            const int r = c * 8 + (lane >> 3);           // LDS row: scene r / (16*RB), token r % (16*RB); padding rows re-fetch row 0
+            const int sc = r / (16 * RB), tk = r % (16 * RB), gr = sc * p.ntok + tk;
+            dvoff[i] = (tk < p.ntok && gr < rows_here ? gr : 0) * p.lda * 4 + (((lane & 7) ^ (r & 7)) << 4);
         } else {                                         // 16 channel rows x 64 B of one plane; k-octet g lands in slot g ^ ((n >> 1) & 3)
             const int cbk = c - CH_A, plane = cbk / CH_PL, nrow = (cbk % CH_PL) * 16 + (lane >> 2);
             dvoff[i] = plane * plane_bytes + nrow * p.k * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4);
@@ -164,21 +170,21 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     };
 
     // accumulators: out^T blocks, lane = (token lane&15, channels 4*(lane>>4) .. +3); bias folded into the initial value
-    f32x4 acc[5][4];
+    f32x4 acc[RB][4];
     const int g = lane >> 4, l15 = lane & 15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) b4 = *(const f32x4*)(p.bias + col0 + wn * 64 + j * 16 + 4 * g);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) acc[i][j] = b4;
+        for (int i = 0; i < RB; ++i) acc[i][j] = b4;
     }
 
     // per-lane LDS byte offsets of the fragments inside a stage
-    int aoff[5][2], woff[4];
+    int aoff[RB][2], woff[4];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int r = wm * 80 + i * 16 + l15;
+    for (int i = 0; i < RB; ++i) {
+        const int r = (wm * RB + i) * 16 + l15;
         aoff[i][0] = r * 128 + (((2 * g) ^ (r & 7)) << 4);
         aoff[i][1] = r * 128 + (((2 * g + 1) ^ (r & 7)) << 4);
     }
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(st + woff[j] + pl * B_PLANE);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 const f32x4 lo = *(const f32x4*)(st + aoff[i][0]), hi = *(const f32x4*)(st + aoff[i][1]);
                 bf16x8 x1, x2, x3;
                 split8(lo, hi, x1, x2, x3);
@@ -247,22 +253,24 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(st + woff[j] + pl * B_PLANE);
-            raw[1][0] = *(const f32x4*)(st + aoff[1][0]);
-            raw[1][1] = *(const f32x4*)(st + aoff[1][1]);
+            if constexpr (RB > 1) {
+                raw[1][0] = *(const f32x4*)(st + aoff[1][0]);
+                raw[1][1] = *(const f32x4*)(st + aoff[1][1]);
+            }
             split8(raw[0][0], raw[0][1], xs[0][0], xs[0][1], xs[0][2]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                if (i + 2 < 5) {
+            for (int i = 0; i < RB; ++i) {
+                if (i + 2 < RB) {
                     raw[i & 1][0] = *(const f32x4*)(st + aoff[i + 2][0]);
                     raw[i & 1][1] = *(const f32x4*)(st + aoff[i + 2][1]);
                 }
-                if (i + 1 < 5)
+                if (i + 1 < RB)
                     split8(raw[(i + 1) & 1][0], raw[(i + 1) & 1][1], xs[(i + 1) & 1][0], xs[(i + 1) & 1][1], xs[(i + 1) & 1][2]);
                 mma_block(wf, xs[i & 1][0], xs[i & 1][1], xs[i & 1][2], acc[i]);
-                if (i + 1 < 5) {
+                if (i + 1 < RB) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i + 2 < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if (i + 2 < RB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
                     for (int q = 0; q < NMMA - 2; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -274,11 +282,12 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             }
         }
     } else {
-        // PIPE 2: the pipeline runs ACROSS K tiles.  Block s = 5*kt + i: its MFMAs use the split made under block s-1's MFMAs
-        // from the f32 fragment read under block s-2's.  Tile kt+1 is confirmed (vmcnt(0) + barrier) at the start of block 3
-        // of tile kt: by then every fragment of tile kt is in registers, so the same barrier frees stage kt&1 for the DMA
-        // of tile kt+2, and blocks 3/4 read tile kt+1's first token fragments and its weight planes (second register set).
-        // No exposed split or LDS latency per tile; the tail issues harmless duplicate DMAs / reads instead of branching.
+        // PIPE 2: the pipeline runs ACROSS K tiles.  Block s = RB*kt + i: its MFMAs use the split made under block s-1's MFMAs
+        // from the f32 fragment read under block s-2's.  Tile kt+1 is confirmed (vmcnt(0) + barrier) at the start of block
+        // B0 = RB-2 of tile kt: by then every fragment of tile kt is in registers, so the same barrier frees stage kt&1 for the
+        // DMA of tile kt+2, and blocks B0, B0+1 read tile kt+1's first token fragments and its weight planes (second register
+        // set).  No exposed split or LDS latency per tile; the tail issues harmless duplicate DMAs / reads instead of branching.
+        constexpr int B0 = RB - 2;
         bf16x8 wfA[4][3], wfB[4][3];
         f32x4 raw[2][2];
         bf16x8 xs[2][3];
@@ -296,25 +305,25 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
         split8(raw[0][0], raw[0][1], xs[0][0], xs[0][1], xs[0][2]);
         __builtin_amdgcn_sched_barrier(0);
         auto tile = [&](auto par_c, int kt, const bf16x8 (&wfc)[4][3], bf16x8 (&wfn)[4][3]) {
-            constexpr int PAR = decltype(par_c)::value;          // kt & 1 == PAR; block parity of block i is (PAR + i) & 1
+            constexpr int PAR = decltype(par_c)::value;          // kt & 1 == PAR; block i of this tile has parity (PAR*RB + i) & 1
             const char* cur = smem + PAR * STAGE;
             const char* nxt = smem + (PAR ^ 1) * STAGE;
             auto block = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
-                constexpr int sp = (PAR + i) & 1;
-                if constexpr (i == 3) {
+                constexpr int sp = (PAR * RB + i) & 1;
+                if constexpr (i == B0) {
                     __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): tile kt+1 landed, my reads of tile kt done
                     __syncthreads();
                     dma_tile(min(kt + 2, KT - 1), const_cast<char*>(cur));
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const char* src = i + 2 < 5 ? cur : nxt;
-                constexpr int blk = i + 2 < 5 ? i + 2 : i + 2 - 5;
+                const char* src = i + 2 < RB ? cur : nxt;
+                constexpr int blk = i + 2 < RB ? i + 2 : i + 2 - RB;
                 raw[sp][0] = *(const f32x4*)(src + aoff[blk][0]);
                 raw[sp][1] = *(const f32x4*)(src + aoff[blk][1]);
-                if constexpr (i >= 3) {
+                if constexpr (i >= B0) {
 #pragma unroll
-                    for (int j = 2 * (i - 3); j < 2 * (i - 3) + 2; ++j)
+                    for (int j = 2 * (i - B0); j < 2 * (i - B0) + 2; ++j)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) wfn[j][pl] = *(const bf16x8*)(nxt + woff[j] + pl * B_PLANE);
                 }
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                 mma_block(wfc, xs[sp][0], xs[sp][1], xs[sp][2], acc[i]);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                if constexpr (i >= 3) {
+                if constexpr (i >= B0) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -330,18 +339,19 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < NMMA - 2 - (i >= 3 ? 3 : 0); ++q) {
+                for (int q = 0; q < NMMA - 2 - (i >= B0 ? 3 : 0); ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2) + (i >= 3 ? 1 : 0), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2) + (i >= B0 ? 1 : 0), 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
             };
             block(std::integral_constant<int, 0>{});
             block(std::integral_constant<int, 1>{});
-            block(std::integral_constant<int, 2>{});
-            block(std::integral_constant<int, 3>{});
-            block(std::integral_constant<int, 4>{});
+            if constexpr (RB > 2) block(std::integral_constant<int, 2>{});
+            if constexpr (RB > 3) block(std::integral_constant<int, 3>{});
+            if constexpr (RB > 4) block(std::integral_constant<int, 4>{});
+            static_assert(RB <= 5, "blocks are spelled out up to 5");
         };
         for (int kt = 0; kt < KT; kt += 2) {                     // KT is even (host checks k % 64 == 0)
             tile(std::integral_constant<int, 0>{}, kt, wfA, wfB);
@@ -350,13 +360,18 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
 
-    float* const ob = p.out + (int64_t)row0 * p.ldc + col0 + wn * 64 + 4 * g;
-    if constexpr (!GN) {
-        const float* const rbp = p.residual ? p.residual + (int64_t)row0 * p.ldr + col0 + wn * 64 + 4 * g : nullptr;
+    // epilogue: lane = token (block i, row l15) x 4 consecutive channels per MFMA block j; wave = scene wm x group wn
+    const int cbase = col0 + wn * 64 + 4 * g;
+    const int srow = wm * p.ntok;                        // first row of this wave's scene, relative to row0
+    bool valid[RB];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int r = wm * 80 + i * 16 + l15;
-            if (r < rows_here) {
+    for (int i = 0; i < RB; ++i) valid[i] = i * 16 + l15 < p.ntok && srow + i * 16 + l15 < rows_here;
+    float* const ob = p.out + (int64_t)(row0 + srow + l15) * p.ldc + cbase;
+    const float* const rbp = p.residual ? p.residual + (int64_t)(row0 + srow + l15) * p.ldr + cbase : nullptr;
+    if constexpr (!GN) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            if (valid[i]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 y = acc[i][j];
@@ -367,23 +382,23 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.f + __expf(-y[e]));
                     }
-                    if (rbp) y += *(const f32x4*)(rbp + (int64_t)r * p.ldr + j * 16);
-                    *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = y;
+                    if (rbp) y += *(const f32x4*)(rbp + (int64_t)i * 16 * p.ldr + j * 16);
+                    *(f32x4*)(ob + (int64_t)i * 16 * p.ldc + j * 16) = y;
                 }
             }
         }
     } else {
-        // The wave tile IS one GroupNorm cell: 80 tokens of scene (row0 / 80 + wm) x the 64 channels of group (col0 / 64 + wn).
-        // Statistics are wave-local (two passes over the 80 accumulators of a lane + a wave sum): no LDS, no block barrier.
-        const int cbase = col0 + wn * 64 + 4 * g;
-        const int scene = row0 / 80 + wm;
+        // The wave tile IS one GroupNorm cell: the ntok tokens of scene (row0 / ntok + wm) x the 64 channels of group
+        // (col0 / 64 + wn).  Statistics are wave-local (two passes over the lane's accumulators + a wave sum; padding rows
+        // masked): no LDS, no block barrier.
+        const int scene = row0 / p.ntok + wm;
         f32x4 ga[4], be[4], sc[4], sh[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                    // issued first: their latency hides under the statistics
             ga[j] = *(const f32x4*)(p.gamma + cbase + j * 16);
             be[j] = *(const f32x4*)(p.beta + cbase + j * 16);
             if (p.scale_shift) {
-                const float* ssr = p.scale_shift + (int64_t)min(scene, p.m / 80 - 1) * p.ld_ss + cbase + j * 16;
+                const float* ssr = p.scale_shift + (int64_t)min(scene, p.m / p.ntok - 1) * p.ld_ss + cbase + j * 16;
                 sc[j] = *(const f32x4*)ssr;
                 sh[j] = *(const f32x4*)(ssr + p.n);
             } else {
@@ -396,23 +411,25 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             return v;
         };
+        const float inv_cnt = 1.f / (float)(p.ntok * 64);
         float s0 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s0 += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-        const float mean = wave_sum(s0) * (1.f / 5120.f);
+            for (int j = 0; j < 4; ++j)
+                s0 += valid[i] ? (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]) : 0.f;
+        const float mean = wave_sum(s0) * inv_cnt;
         float q0 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = acc[i][j][e] - mean;
+                    const float d = valid[i] ? acc[i][j][e] - mean : 0.f;
                     q0 = fmaf(d, d, q0);
                 }
-        const float rstd = 1.f / sqrtf(wave_sum(q0) * (1.f / 5120.f) + p.eps);
+        const float rstd = 1.f / sqrtf(wave_sum(q0) * inv_cnt + p.eps);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -421,11 +438,9 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                 ga[j][e] = a * sp1;
                 be[j][e] = fmaf(be[j][e] - mean * a, sp1, sh[j][e]);
             }
-        const float* const rbp = p.residual ? p.residual + (int64_t)row0 * p.ldr + cbase : nullptr;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int r = wm * 80 + i * 16 + l15;
-            if (r < rows_here) {
+        for (int i = 0; i < RB; ++i) {
+            if (valid[i]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 y;
@@ -434,8 +449,8 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                         const float t = fmaf(acc[i][j][e], ga[j][e], be[j][e]);
                         y[e] = t / (1.f + __expf(-t));
                     }
-                    if (rbp) y += *(const f32x4*)(rbp + (int64_t)r * p.ldr + j * 16);
-                    *(f32x4*)(ob + (int64_t)r * p.ldc + j * 16) = y;
+                    if (rbp) y += *(const f32x4*)(rbp + (int64_t)i * 16 * p.ldr + j * 16);
+                    *(f32x4*)(ob + (int64_t)i * 16 * p.ldc + j * 16) = y;
                 }
             }
         }
@@ -444,25 +459,26 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 
 }  // namespace
 
-// One launcher for every variant.  gn: fused Block epilogue (scenes of exactly 80 tokens).  products: 6 = f32-accurate,
-// 3 = "bf16x3" (about 2^-17), 1 = plain bf16 (the pipe's ceiling with the same data movement).  pipe: 0 compiler-scheduled,
-// 1 split pipelined inside a K tile, 2 across K tiles.  tile: 0 = 160 x 256 when n % 256 == 0 else 320 x 128; 1 / 2 force one.
-template <int WM, int WN>
+// One launcher for every variant.  gn: fused Block epilogue.  products: 6 = f32-accurate, 3 = "bf16x3" (about 2^-17),
+// 1 = plain bf16 (the pipe's ceiling with the same data movement).  pipe: 0 compiler-scheduled, 1 split pipelined inside a K
+// tile, 2 across K tiles.
+template <int WM, int WN, int RB>
 static int launch_cfg(const Args& a, int gn, int products, int pipe, hipStream_t s) {
-    using C = Cfg<WM, WN>;
-    if (a.n % C::BN) return 2;
-    if ((int64_t)C::BM * a.lda * 4 >= 0x7fffffffLL || 3LL * a.n * a.k * 2 >= 0x7fffffffLL) return 3;   // 32-bit DMA offsets
-    const unsigned grid = (unsigned)(((a.m + C::BM - 1) / C::BM) * (a.n / C::BN));
+    using C = Cfg<WM, WN, RB>;
+    if (a.n % C::BN || a.ntok > 16 * RB || a.ntok <= 0) return 2;
+    if ((int64_t)WM * a.ntok * a.lda * 4 >= 0x7fffffffLL || 3LL * a.n * a.k * 2 >= 0x7fffffffLL) return 3;   // 32-bit DMA offsets
+    const int scenes = (a.m + a.ntok - 1) / a.ntok;
+    const unsigned grid = (unsigned)(((scenes + WM - 1) / WM) * (a.n / C::BN));
     if (gn) {
-        if (products != 6) return 2;
-        if (pipe == 1) gemm_bf16_split_kernel<6, 1, true, WM, WN><<<grid, T, 0, s>>>(a);
-        else if (pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, true, WM, WN><<<grid, T, 0, s>>>(a);
+        if (products != 6 || a.m % a.ntok) return 2;
+        if (pipe == 1) gemm_bf16_split_kernel<6, 1, true, WM, WN, RB><<<grid, T, 0, s>>>(a);
+        else if (pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, true, WM, WN, RB><<<grid, T, 0, s>>>(a);
         else return 2;
-    } else if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0, false, WM, WN><<<grid, T, 0, s>>>(a);
-    else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1, false, WM, WN><<<grid, T, 0, s>>>(a);
-    else if (products == 6 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, false, WM, WN><<<grid, T, 0, s>>>(a);
-    else if (products == 3 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<3, 2, false, WM, WN><<<grid, T, 0, s>>>(a);
-    else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0, false, WM, WN><<<grid, T, 0, s>>>(a);
+    } else if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
+    else if (products == 3 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<3, 2, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
+    else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
     else return 2;
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -475,15 +491,20 @@ int bf16x6_split_planes(const float* w, long count, uint16_t* planes, hipStream_
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+// tile: 0 = automatic, 1 = 2x4 waves (160 x 256 at RB 5), 2 = 4x2 waves (320 x 128 at RB 5).  ntok: tokens per scene for the
+// fused epilogue (80 -> RB 5; <= 32, e.g. 21 -> RB 2 with 4 scenes x 128 channels per block); 0 = dense rows (plain GEMM, RB 5).
 int bf16x6_launch(const float* x, const float* x2, int k1, int lda, const uint16_t* planes, const float* bias, float* out, int ldc,
                   int m, int n, int k, int act, const float* residual, int ldr, int gn, const float* gamma, const float* beta,
-                  float eps, const float* scale_shift, int ld_ss, int products, int pipe, int tile, hipStream_t s) {
+                  float eps, const float* scale_shift, int ld_ss, int ntok, int products, int pipe, int tile, hipStream_t s) {
     if (k % BK || k1 % BK || k1 <= 0 || k1 > k || (k1 < k && !x2) || (lda & 3) || (ldc & 3) || (ldr & 3) || (ld_ss & 3) || m <= 0)
         return 2;
-    if (gn && (m % 80 || !gamma || !beta)) return 2;
-    Args a{x, k1 < k ? x2 : nullptr, k1, planes, bias, out, m, n, k, lda, ldc, gamma, beta, eps, scale_shift, ld_ss, residual, ldr, act};
-    if (tile == 1 || (tile == 0 && n % 256 == 0)) return launch_cfg<2, 4>(a, gn, products, pipe, s);
-    return launch_cfg<4, 2>(a, gn, products, pipe, s);
+    if (gn && (ntok <= 0 || !gamma || !beta)) return 2;
+    const bool small = ntok > 0 && ntok <= 32;
+    Args a{x, k1 < k ? x2 : nullptr, k1, planes, bias, out, m, n, k, lda, ldc, small ? ntok : (ntok > 0 ? ntok : 80),
+           gamma, beta, eps, scale_shift, ld_ss, residual, ldr, act};
+    if (small) return launch_cfg<4, 2, 2>(a, gn, products, pipe, s);
+    if (tile == 1 || (tile == 0 && n % 256 == 0)) return launch_cfg<2, 4, 5>(a, gn, products, pipe, s);
+    return launch_cfg<4, 2, 5>(a, gn, products, pipe, s);
 }
 
 }  // extern "C"

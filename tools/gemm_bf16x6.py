@@ -45,17 +45,18 @@ def main():
     lib.bf16x6_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,   # x x2 k1 lda planes bias out ldc
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,                                # m n k act residual ldr
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,                        # gn gamma beta eps ss ld_ss
-                                  C.c_int, C.c_int, C.c_int, C.c_void_p]                                                  # products pipe tile stream
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]                                         # ntok products pipe tile stream
 
     def ptr(t):
         return t.data_ptr() if t is not None else None
 
-    def launch6(xin, planes_t, bias, out, m, n, k, products, pipe, x2=None, k1=None, act=0, residual=None, gn=None, tile=0, stream=None):
+    def launch6(xin, planes_t, bias, out, m, n, k, products, pipe, x2=None, k1=None, act=0, residual=None, gn=None, tile=0, stream=None,
+                ntok=0):
         gamma, beta, ss = gn if gn is not None else (None, None, None)
         rc = lib.bf16x6_launch(ptr(xin), ptr(x2), k if k1 is None else k1, xin.stride(0), ptr(planes_t), ptr(bias), ptr(out), out.stride(0),
                                m, n, k, act, ptr(residual), residual.stride(0) if residual is not None else 0,
                                1 if gn is not None else 0, ptr(gamma), ptr(beta), 1e-5, ptr(ss), ss.stride(0) if ss is not None else 0,
-                               products, pipe, tile, stream)
+                               ntok if ntok else (80 if gn is not None else 0), products, pipe, tile, stream)
         assert rc == 0, ("bf16x6_launch", rc, products, pipe)
 
     dev = torch.device("cuda:0")
@@ -248,6 +249,51 @@ def main():
             torch.cuda.synchronize()
             tt[name] = e0.elapsed_time(e1) * 1000.0 / 30
             print("K=%4d  n=384  %-24s %7.1f us  %6.1f TF f32-equivalent" % (K, name, tt[name], 2.0 * M * n3 * K / tt[name] / 1e6), flush=True)
+
+
+    # 7. scenes of 21 tokens (BASELINE config 2: B = 256, N = 21): 4 scenes x 128 channels per block, scenes padded to 32 rows in LDS
+    B2, N2, K = 256, 21, 512
+    M2 = B2 * N2
+    x = torch.nn.functional.silu(torch.randn(M2, K, device=dev)) * 1.3
+    w = torch.randn(NOUT, K, device=dev) / K ** 0.5
+    b = torch.randn(NOUT, device=dev) * 0.1
+    planes = torch.empty(3, NOUT, K, device=dev, dtype=torch.int16)
+    assert lib.bf16x6_split_planes(w.data_ptr(), w.numel(), planes.data_ptr(), s) == 0
+    gamma, beta = torch.rand(NOUT, device=dev) + 0.5, torch.randn(NOUT, device=dev) * 0.1
+    ss = torch.randn(B2, 2 * NOUT, device=dev) * 0.1
+    res = torch.randn(M2, NOUT, device=dev)
+    ref = x.double() @ w.double().t() + b.double()
+    z = ref.view(B2, N2, NOUT // 64, 64)
+    mu, var = z.mean(dim=(1, 3), keepdim=True), z.var(dim=(1, 3), unbiased=False, keepdim=True)
+    zn = ((z - mu) / (var + 1e-5).sqrt()).view(B2, N2, NOUT) * gamma.double() + beta.double()
+    zn = zn * (ss[:, None, :NOUT].double() + 1) + ss[:, None, NOUT:].double()
+    ref_gn = (zn * torch.sigmoid(zn)).view(M2, NOUT) + res.double()
+    rms_gn = float(ref_gn.pow(2).mean().sqrt())
+    yp = torch.empty(M2, NOUT, device=dev)
+    ggn = ops.make_gemm_args(x, w, yp, b, None, res, gamma=gamma, beta=beta, tokens_per_scene=N2, scale_shift=ss, ss_mode=2)
+    ops.run_gemm(ggn, gn=True)
+    y21 = torch.zeros(M2, NOUT, device=dev)
+    torch.cuda.synchronize()
+    print("N=21  GN  dsc_gemm_gn_silu_f32          max %.2e" % (float((yp.double() - ref_gn).abs().max()) / rms_gn), flush=True)
+    for pp in (1, 2):
+        y21.zero_()
+        launch6(x, planes, b, y21, M2, NOUT, K, 6, pp, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)
+        torch.cuda.synchronize()
+        print("N=21  GN  bf16 split x6 pipe=%d          max %.2e" % (pp, float((y21.double() - ref_gn).abs().max()) / rms_gn), flush=True)
+    for name, fn in (("dsc_gemm_gn_silu_f32", lambda: ops.run_gemm(ggn, gn=True)),
+                     ("bf16 split x6 pipe=1", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 1, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)),
+                     ("bf16 split x6 pipe=2", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 2, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2))):
+        for _ in range(50):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1000.0 / 50
+        print("N=21  GN  %-24s %7.1f us  %6.1f TF f32-equivalent (%.3f of the f32-MFMA peak)" % (
+            name, us, 2.0 * M2 * NOUT * K / us / 1e6, 2.0 * M2 * NOUT * K / us / 1e6 / 157.3), flush=True)
 
 
 if __name__ == "__main__":

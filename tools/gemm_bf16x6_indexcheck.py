@@ -9,16 +9,16 @@ import numpy as np
 BK, NW = 32, 8
 
 
-def main(WM, WN):
+def main(WM, WN, RB, ntok, scenes_total, tail=0):
     global BM, BN, A_STAGE, B_PLANE
     FR.clear(); FW.clear()
-    BM, BN = 80 * WM, 64 * WN
+    BM, BN = 16 * RB * WM, 64 * WN                          # LDS rows (scenes padded to 16*RB); global rows per block = WM * ntok
     A_STAGE, B_PLANE = BM * BK * 4, BN * BK * 2
     CH_A, CH_PL = A_STAGE // 1024, B_PLANE // 1024
     CH = CH_A + 3 * CH_PL
     NI = (CH + NW - 1) // NW
     rng = np.random.default_rng(0)
-    M, N, K, K1 = 2 * BM, 2 * BN, 96, 64                    # two K segments: 64 columns from x, 32 from x2
+    M, N, K, K1 = scenes_total * ntok - tail, 2 * BN, 96, 64   # two K segments: 64 columns from x, 32 from x2; tail: dense GEMM whose m is not a multiple of 16*RB
     lda = 64 + 8                                            # a row stride that is not K (the same for both segments)
     x = rng.standard_normal((M, lda)).astype(np.float32)
     x2 = rng.standard_normal((M, lda)).astype(np.float32)
@@ -28,14 +28,16 @@ def main(WM, WN):
     xbytes = x.view(np.uint8).reshape(-1)
     pbytes = planes.view(np.uint8).reshape(-1)
     out = np.zeros((M, N), np.float64)
-    rbs, cbs = M // BM, N // BN
+    written = np.zeros((M, N), bool)
+    rbs, cbs = (scenes_total + WM - 1) // WM, N // BN
     for blk in range(rbs * cbs):
         rb, cb = blk // cbs, blk % cbs                      # (the XCD remap only permutes blocks)
-        row0, col0 = rb * BM, cb * BN
+        row0, col0 = rb * WM * ntok, cb * BN
+        rows_here = M - row0
         xb = row0 * lda * 4                                 # byte offset of the block's first token row
         wb = col0 * K * 2                                   # byte offset of the block's first channel row in plane 0
         plane_bytes = N * K * 2
-        acc = np.zeros((NW, 5, 4, 64, 4), np.float64)
+        acc = np.zeros((NW, RB, 4, 64, 4), np.float64)
         for kt in range(K // BK):
             k0 = kt * BK
             lds = np.zeros(A_STAGE + 3 * B_PLANE, np.uint8)
@@ -47,7 +49,9 @@ def main(WM, WN):
                     for lane in range(64):
                         if c < CH_A:
                             r = c * 8 + (lane >> 3)
-                            voff = r * lda * 4 + (((lane & 7) ^ (r & 7)) << 4)
+                            sc, tk = r // (16 * RB), r % (16 * RB)
+                            gr = sc * ntok + tk
+                            voff = (gr if (tk < ntok and gr < rows_here) else 0) * lda * 4 + (((lane & 7) ^ (r & 7)) << 4)
                             seg1 = k0 < K1
                             sb, sx = (xbytes, k0 * 4) if seg1 else (x2bytes, (k0 - K1) * 4)
                             src = sb[xb + voff + sx: xb + voff + sx + 16]
@@ -68,8 +72,8 @@ def main(WM, WN):
                         for pl in range(3):
                             wf[j, pl] = lds[woff + pl * B_PLANE: woff + pl * B_PLANE + 16].view(np.int16)
                     acc_lane_w = wf
-                    for i in range(5):
-                        r = wm * 80 + i * 16 + l15
+                    for i in range(RB):
+                        r = (wm * RB + i) * 16 + l15
                         a0 = r * 128 + (((2 * g) ^ (r & 7)) << 4)
                         a1 = r * 128 + (((2 * g + 1) ^ (r & 7)) << 4)
                         xf = np.concatenate([lds[a0:a0 + 16].view(np.float32), lds[a1:a1 + 16].view(np.float32)]).astype(np.float64)
@@ -79,7 +83,7 @@ def main(WM, WN):
             # MFMA 16x16x32: D[row][col] += sum_k A[row][k] B[k][col]; lane l holds A[l&15][8*(l>>4)+e], B[8*(l>>4)+e][l&15];
             # result lane l, reg e: row 4*(l>>4)+e, col l&15.  A = weight fragment (plane sum stands for the six products), B = tokens.
             for wave in range(NW):
-                for i in range(5):
+                for i in range(RB):
                     for j in range(4):
                         Amat = np.zeros((16, 32))
                         Bmat = np.zeros((32, 16))
@@ -95,33 +99,38 @@ def main(WM, WN):
             wm, wn = wave % WM, wave // WM
             for lane in range(64):
                 g, l15 = lane >> 4, lane & 15
-                for i in range(5):
-                    r = wm * 80 + i * 16 + l15
+                srow = wm * ntok
+                for i in range(RB):
+                    if not (i * 16 + l15 < ntok and srow + i * 16 + l15 < rows_here):
+                        continue
                     for j in range(4):
                         n = col0 + wn * 64 + 4 * g + j * 16
-                        out[row0 + r, n: n + 4] = acc[wave, i, j, lane]
+                        assert not written[row0 + srow + i * 16 + l15, n]
+                        written[row0 + srow + i * 16 + l15, n: n + 4] = True
+                        out[row0 + srow + i * 16 + l15, n: n + 4] = acc[wave, i, j, lane]
     xcat = np.concatenate([x[:, :K1], x2[:, :K - K1]], axis=1)
     ref = xcat.astype(np.float64) @ planes.astype(np.float64).sum(axis=0).T
+    assert written.all(), "some outputs were never stored"
     err = np.abs(out - ref).max()
-    print("tile %d x %d: max |emulated kernel - [x | x2].w^T| = %.3e over %d x %d outputs (K = %d + %d, 2 x 2 blocks)" % (
-        BM, BN, err, M, N, K1, K - K1))
+    print("waves %d x %d, RB %d, %d tokens/scene, %d scenes: max |emulated kernel - [x | x2].w^T| = %.3e over %d x %d outputs (K = %d + %d)" % (
+        WM, WN, RB, ntok, scenes_total, err, M, N, K1, K - K1))
     assert err < 1e-9 * max(1.0, np.abs(ref).max())
     print("index arithmetic consistent")
 
 
-def bank_check(WM, WN):
+def bank_check(WM, WN, RB):
     """ds_read_b128: the LDS serves 128 B per clock = 8 lanes x 16 B; conflict-free when each run of 8 consecutive lanes touches
     8 distinct 16-byte bank groups ((address / 16) mod 8)."""
     worst = 1
-    A_STAGE = 80 * WM * BK * 4
+    A_STAGE = 16 * RB * WM * BK * 4
     for wave in range(NW):
         wm, wn = wave % WM, wave // WM
-        for i in range(5):
+        for i in range(RB):
             for half in range(2):
                 ad = []
                 for lane in range(64):
                     g, l15 = lane >> 4, lane & 15
-                    r = wm * 80 + i * 16 + l15
+                    r = (wm * RB + i) * 16 + l15
                     ad.append(r * 128 + (((2 * g + half) ^ (r & 7)) << 4))
                 for q in range(8):
                     grp = [(a >> 4) & 7 for a in ad[8 * q: 8 * q + 8]]
@@ -135,12 +144,13 @@ def bank_check(WM, WN):
             for q in range(8):
                 grp = [(a >> 4) & 7 for a in ad[8 * q: 8 * q + 8]]
                 worst = max(worst, max(grp.count(v) for v in grp))
-    print("tile %d x %d fragment reads: worst bank-group multiplicity within 8 consecutive lanes = %d (1 = conflict-free)" % (80 * WM, 64 * WN, worst))
+    print("waves %d x %d, RB %d fragment reads: worst bank-group multiplicity within 8 consecutive lanes = %d (1 = conflict-free)" % (WM, WN, RB, worst))
     assert worst == 1
 
 
 FR, FW = {}, {}
 if __name__ == "__main__":
-    for cfg in ((2, 4), (4, 2)):
+    # (WM, WN, RB, tokens per scene, scenes): the 80-token tiles, a ragged scene count, 21-token scenes, a dense GEMM with a row tail
+    for cfg in ((2, 4, 5, 80, 4), (4, 2, 5, 80, 5), (4, 2, 2, 21, 7), (2, 4, 5, 80, 3), (2, 4, 5, 80, 4, 70)):
         main(*cfg)
-        bank_check(*cfg)
+        bank_check(*cfg[:3])
