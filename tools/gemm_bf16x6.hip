@@ -45,6 +45,7 @@ struct Cfg {
     static constexpr int STAGE = A_STAGE + 3 * B_PLANE;
     static constexpr int CH_A = A_STAGE / 1024, CH_PL = B_PLANE / 1024, CH = CH_A + 3 * CH_PL;   // one-KiB wave transfers
     static constexpr int NI = (CH + NW - 1) / NW;                // per wave (a ragged last round re-fetches chunks 0..: same bytes)
+    static constexpr bool P3 = 2 * (3 * BM * BK * 2 + 3 * B_PLANE) <= 160 * 1024;   // PIPE 3 (x staged as three bf16 planes) fits two stages
 };
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
@@ -109,9 +110,16 @@ template <int PRODUCTS, int PIPE, bool GN = false, int WM = 2, int WN = 4, int R
 __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
     static_assert(PIPE != 2 || RB >= 2, "the cross-tile pipeline reads two blocks ahead: one-block scenes would need a third stage");
     using C = Cfg<WM, WN, RB>;
-    constexpr int BM = C::BM, BN = C::BN, A_STAGE = C::A_STAGE, B_PLANE = C::B_PLANE, STAGE = C::STAGE, CH_A = C::CH_A,
-                  CH_PL = C::CH_PL, CH = C::CH, NI = C::NI;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int BM = C::BM, BN = C::BN, B_PLANE = C::B_PLANE, CH_PL = C::CH_PL;
+    // per-stage LDS: [x region | 3 weight planes].  PIPE 0-2: x is the f32 tile, filled by DMA.  PIPE 3: x is three bf16
+    // planes [3][BM][32] written by the staging threads (split once per block), only the weights come by DMA.
+    constexpr int X_PLANE = BM * BK * 2;
+    constexpr int XA = PIPE == 3 ? 3 * X_PLANE : C::A_STAGE;
+    constexpr int STAGE = XA + 3 * B_PLANE;
+    constexpr int CH_A = PIPE == 3 ? 0 : C::CH_A, CH = CH_A + 3 * CH_PL, NI = (CH + NW - 1) / NW;
+    constexpr int DUMP = (PIPE == 3 && (BM * 4 / NW) % 64) ? 1024 : 0;     // PIPE 3: where the idle lanes of a ragged item round write
+    static_assert(2 * STAGE + DUMP <= 160 * 1024, "two stages must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + DUMP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave_u % WM, wn = wave_u / WM;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 isx ? (void*)const_cast<float*>(xs_) : (void*)const_cast<uint16_t*>(wb), 0, 0x7fffffff, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lbase + c * 1024, 16, dvoff[i], isx ? sx : k0 * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lbase + (isx ? c * 1024 : XA + (c - CH_A) * 1024), 16, dvoff[i], isx ? sx : k0 * 2, 0, 0);
 #else
             (void)isx; (void)sx; (void)xs_; (void)lbase;
 #endif
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int nr = wn * 64 + j * 16 + l15;
-        woff[j] = A_STAGE + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4);
+        woff[j] = XA + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4);
     }
 
     const int KT = p.k / BK;
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    } else {
+    } else if constexpr (PIPE == 2) {
         // PIPE 2: the pipeline runs ACROSS K tiles.  Block s = RB*kt + i: its MFMAs use the split made under block s-1's MFMAs
         // from the f32 fragment read under block s-2's.  Tile kt+1 is confirmed (vmcnt(0) + barrier) at the start of block
         // B0 = RB-2 of tile kt: by then every fragment of tile kt is in registers, so the same barrier frees stage kt&1 for the
@@ -356,6 +364,103 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
         for (int kt = 0; kt < KT; kt += 2) {                     // KT is even (host checks k % 64 == 0)
             tile(std::integral_constant<int, 0>{}, kt, wfA, wfB);
             tile(std::integral_constant<int, 1>{}, kt + 1, wfB, wfA);
+        }
+    } else {
+        // PIPE 3: split ONCE per block.  The staging threads load the f32 token tile of K tile kt+1 into registers (8
+        // consecutive k of one token row per item, 1 or 2 items per lane), split it under the MFMAs of tile kt and write three
+        // bf16 planes [3][BM][32] into the other LDS stage -- the same row layout and swizzle as the weight planes -- so a token
+        // fragment is three 16-byte reads and no wave repeats the split of rows it shares with the other WN-1 waves (44 VALU
+        // per item instead of 44 per 16-token block and wave: 88 instead of 220 per wave and tile at 160 x 256).
+        constexpr int ITEMS_W = BM * 4 / NW;                 // (row, k-octet) items per wave
+        constexpr int NIT = (ITEMS_W + 63) / 64;             // per lane: 1 (BM = 128) or 2 (BM = 160: lanes 0..15 take a second one)
+        static_assert(NIT <= RB && NIT <= 2, "the splits ride in the last NIT token blocks of a tile");
+        int ivoff[NIT], ildso[NIT];
+        bool ion[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int idx = 64 * u + lane;
+            ion[u] = idx < ITEMS_W;
+            const int t = wave_u * ITEMS_W + (ion[u] ? idx : 0);
+            const int r = t >> 2, q = t & 3;                 // LDS row, k-octet
+            const int sc = r / (16 * RB), tk = r % (16 * RB), gr = sc * p.ntok + tk;
+            ivoff[u] = (tk < p.ntok && gr < rows_here ? gr : 0) * p.lda * 4 + q * 32;
+            ildso[u] = r * 64 + ((q ^ ((r >> 1) & 3)) << 4);
+        }
+        int xoff[RB];                                        // token fragment of block i: row (wm*RB+i)*16 + l15, k-octet g
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int r = (wm * RB + i) * 16 + l15;
+            xoff[i] = r * 64 + ((g ^ ((r >> 1) & 3)) << 4);
+        }
+        f32x4 ld[NIT][2];
+        auto load_items = [&](int kt) {
+            const int k0 = kt * BK;
+            const bool seg1 = k0 < p.k1;
+            const char* base = (const char*)(seg1 ? xb : xb2) + (seg1 ? k0 : k0 - p.k1) * 4;
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                ld[u][0] = *(const f32x4*)(base + ivoff[u]);
+                ld[u][1] = *(const f32x4*)(base + ivoff[u] + 16);
+            }
+        };
+        auto store_item = [&](int u, char* stage) {
+            bf16x8 a, b, c;
+            split8(ld[u][0], ld[u][1], a, b, c);
+            // idle lanes of a ragged round (they hold a copy of item 0) write to a dump slot instead of being masked off:
+            // an exec-masked store would cut the MFMA stream into basic blocks
+            char* d0 = ion[u] ? stage + ildso[u] : smem + 2 * STAGE + lane * 16;
+            const int ps = ion[u] ? X_PLANE : 0;
+            *(bf16x8*)d0 = a;
+            *(bf16x8*)(d0 + ps) = b;
+            *(bf16x8*)(d0 + 2 * ps) = c;
+        };
+        // prologue: tile 0 -> stage 0 (the weight DMA of tile 0 was issued above)
+        load_items(0);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) store_item(u, smem);
+        for (int kt = 0; kt < KT; ++kt) {
+            __builtin_amdgcn_s_waitcnt(0x0070);              // my DMA chunks and my plane writes of tile kt are done
+            __syncthreads();                                 // everyone's are; nobody reads the other stage any more
+            char* cur = smem + (kt & 1) * STAGE;
+            char* nxt = smem + ((kt + 1) & 1) * STAGE;
+            const int kn = min(kt + 1, KT - 1);              // the tail re-stages the last tile (no branch in the loop)
+            dma_tile(kn, nxt);
+            load_items(kn);
+            bf16x8 wf[4][3], xf[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *(const bf16x8*)(cur + pl * X_PLANE + xoff[0]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(cur + woff[j] + pl * B_PLANE);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                if (i + 1 < RB) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) xf[(i + 1) & 1][pl] = *(const bf16x8*)(cur + pl * X_PLANE + xoff[i + 1]);
+                }
+                if (i == RB - NIT) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);      // the staged f32 rows (and the weight DMA) of the next tile have arrived
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i >= RB - NIT) store_item(i - (RB - NIT), nxt);
+                mma_block(wf, xf[i & 1][0], xf[i & 1][1], xf[i & 1][2], acc[i]);
+                // MFMA first, then the fragment reads of the next block, then the split (2 VALU per MFMA) and its 3 LDS writes
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i + 1 < RB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (i >= RB - NIT) {
+#pragma unroll
+                    for (int q = 0; q < NMMA - 2; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2), 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -461,7 +566,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
 
 // One launcher for every variant.  gn: fused Block epilogue.  products: 6 = f32-accurate, 3 = "bf16x3" (about 2^-17),
 // 1 = plain bf16 (the pipe's ceiling with the same data movement).  pipe: 0 compiler-scheduled, 1 split pipelined inside a K
-// tile, 2 across K tiles.
+// tile, 2 across K tiles, 3 split once per block by the staging threads (token tile kept as three bf16 planes in LDS).
 template <int WM, int WN, int RB>
 static int launch_cfg(const Args& a, int gn, int products, int pipe, hipStream_t s) {
     using C = Cfg<WM, WN, RB>;
@@ -473,10 +578,13 @@ static int launch_cfg(const Args& a, int gn, int products, int pipe, hipStream_t
         if (products != 6 || a.m % a.ntok) return 2;
         if (pipe == 1) gemm_bf16_split_kernel<6, 1, true, WM, WN, RB><<<grid, T, 0, s>>>(a);
         else if (pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, true, WM, WN, RB><<<grid, T, 0, s>>>(a);
+        else if (pipe == 3) { if constexpr (C::P3) gemm_bf16_split_kernel<6, 3, true, WM, WN, RB><<<grid, T, 0, s>>>(a); else return 2; }
         else return 2;
     } else if (products == 6 && pipe == 0) gemm_bf16_split_kernel<6, 0, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
     else if (products == 6 && pipe == 1) gemm_bf16_split_kernel<6, 1, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
     else if (products == 6 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<6, 2, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
+    else if (products == 6 && pipe == 3) { if constexpr (C::P3) gemm_bf16_split_kernel<6, 3, false, WM, WN, RB><<<grid, T, 0, s>>>(a); else return 2; }
+    else if (products == 1 && pipe == 3) { if constexpr (C::P3) gemm_bf16_split_kernel<1, 3, false, WM, WN, RB><<<grid, T, 0, s>>>(a); else return 2; }
     else if (products == 3 && pipe == 2 && a.k % 64 == 0) gemm_bf16_split_kernel<3, 2, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
     else if (products == 1 && pipe == 0) gemm_bf16_split_kernel<1, 0, false, WM, WN, RB><<<grid, T, 0, s>>>(a);
     else return 2;

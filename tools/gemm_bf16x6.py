@@ -62,7 +62,7 @@ def main():
     dev = torch.device("cuda:0")
     B, N = int(opt("--batch", "256")), int(opt("--objects", "80"))
     M, NOUT = B * N, int(opt("--n", "512"))
-    variants = [(6, 0), (6, 1), (6, 2), (3, 2), (1, 0)]          # (products, pipeline)
+    variants = [(6, 0), (6, 1), (6, 2), (6, 3), (3, 2), (1, 0), (1, 3)]          # (products, pipeline); pipeline 3 = split once per block at staging
     torch.manual_seed(0)
     for K in [int(x) for x in opt("--k", "512,1024").split(",")]:
         x = torch.nn.functional.silu(torch.randn(M, K, device=dev)) * 1.3
@@ -87,7 +87,7 @@ def main():
         eye = torch.zeros(M, K, device=dev)
         eye[torch.arange(M, device=dev), torch.arange(M, device=dev) % K] = 1.0
         want = w.t()[torch.arange(M, device=dev) % K] + b
-        for v in variants[:3]:
+        for v in variants[:4]:
             out = torch.zeros(M, NOUT, device=dev)
             run(v, out, eye)
             torch.cuda.synchronize()
@@ -171,21 +171,21 @@ def main():
             ops.run_gemm(ggn, gn=True)
             torch.cuda.synchronize()
             print("K=%d  GN  dsc_gemm_gn_silu_f32          max %.2e  rms %.2e" % ((K,) + err_gn(yp)), flush=True)
-            ygn = {pp: torch.zeros(M, NOUT, device=dev) for pp in (1, 2)}
+            ygn = {pp: torch.zeros(M, NOUT, device=dev) for pp in (1, 2, 3)}
 
             def run_gn(pp):
                 launch6(x, planes, b, ygn[pp], M, NOUT, K, 6, pp, residual=res, gn=(gamma, beta, ss), stream=s)
 
-            for pp in (1, 2):
+            for pp in (1, 2, 3):
                 run_gn(pp)
                 torch.cuda.synchronize()
                 print("K=%d  GN  bf16 split x6 pipe=%d          max %.2e  rms %.2e" % ((K, pp) + err_gn(ygn[pp])), flush=True)
-            names = ["prod", 1, 2]
+            names = ["prod", 1, 2, 3]
             for _ in range(150):
                 ops.run_gemm(ggn, gn=True)
             times = {v: [] for v in names}
             for rnd in range(9):
-                order = names[rnd % 3:] + names[:rnd % 3]
+                order = names[rnd % 4:] + names[:rnd % 4]
                 evs = []
                 for v in order:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -275,14 +275,15 @@ def main():
     y21 = torch.zeros(M2, NOUT, device=dev)
     torch.cuda.synchronize()
     print("N=21  GN  dsc_gemm_gn_silu_f32          max %.2e" % (float((yp.double() - ref_gn).abs().max()) / rms_gn), flush=True)
-    for pp in (1, 2):
+    for pp in (1, 2, 3):
         y21.zero_()
         launch6(x, planes, b, y21, M2, NOUT, K, 6, pp, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)
         torch.cuda.synchronize()
         print("N=21  GN  bf16 split x6 pipe=%d          max %.2e" % (pp, float((y21.double() - ref_gn).abs().max()) / rms_gn), flush=True)
     for name, fn in (("dsc_gemm_gn_silu_f32", lambda: ops.run_gemm(ggn, gn=True)),
                      ("bf16 split x6 pipe=1", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 1, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)),
-                     ("bf16 split x6 pipe=2", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 2, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2))):
+                     ("bf16 split x6 pipe=2", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 2, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)),
+                     ("bf16 split x6 pipe=3", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 3, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2))):
         for _ in range(50):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -9,12 +9,14 @@ import numpy as np
 BK, NW = 32, 8
 
 
-def main(WM, WN, RB, ntok, scenes_total, tail=0):
+def main(WM, WN, RB, ntok, scenes_total, tail=0, pipe3=False):
     global BM, BN, A_STAGE, B_PLANE
     FR.clear(); FW.clear()
     BM, BN = 16 * RB * WM, 64 * WN                          # LDS rows (scenes padded to 16*RB); global rows per block = WM * ntok
     A_STAGE, B_PLANE = BM * BK * 4, BN * BK * 2
-    CH_A, CH_PL = A_STAGE // 1024, B_PLANE // 1024
+    X_PLANE = BM * BK * 2
+    XA = 3 * X_PLANE if pipe3 else A_STAGE                  # PIPE 3: the x region holds three bf16 planes written by the staging threads
+    CH_A, CH_PL = (0 if pipe3 else A_STAGE // 1024), B_PLANE // 1024
     CH = CH_A + 3 * CH_PL
     NI = (CH + NW - 1) // NW
     rng = np.random.default_rng(0)
@@ -40,7 +42,8 @@ def main(WM, WN, RB, ntok, scenes_total, tail=0):
         acc = np.zeros((NW, RB, 4, 64, 4), np.float64)
         for kt in range(K // BK):
             k0 = kt * BK
-            lds = np.zeros(A_STAGE + 3 * B_PLANE, np.uint8)
+            lds = np.zeros(XA + 3 * B_PLANE, np.uint8)
+            xpl = {}                                        # PIPE 3: (plane, byte offset) -> 8 values (exact stand-ins for the bf16 pieces)
             for wave in range(NW):
                 for i in range(NI):
                     c = wave + NW * i
@@ -60,7 +63,27 @@ def main(WM, WN, RB, ntok, scenes_total, tail=0):
                             plane, nrow = cbk // CH_PL, (cbk % CH_PL) * 16 + (lane >> 2)
                             voff = plane * plane_bytes + nrow * K * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4)
                             src = pbytes[wb + voff + k0 * 2: wb + voff + k0 * 2 + 16]
-                        lds[c * 1024 + lane * 16: c * 1024 + lane * 16 + 16] = src
+                        dst = c * 1024 if c < CH_A else XA + (c - CH_A) * 1024
+                        lds[dst + lane * 16: dst + lane * 16 + 16] = src
+                if pipe3:
+                    ITEMS_W = BM * 4 // NW
+                    for u in range((ITEMS_W + 63) // 64):
+                        for lane in range(64):
+                            idx = 64 * u + lane
+                            if idx >= ITEMS_W:
+                                continue                    # (the kernel sends these lanes' copies of item 0 to a dump slot)
+                            t = wave * ITEMS_W + idx
+                            r, q = t >> 2, t & 3
+                            sc, tk = r // (16 * RB), r % (16 * RB)
+                            gr = sc * ntok + tk
+                            ivoff = (gr if (tk < ntok and gr < rows_here) else 0) * lda * 4 + q * 32
+                            seg1 = k0 < K1
+                            sb, sx = (xbytes, k0 * 4) if seg1 else (x2bytes, (k0 - K1) * 4)
+                            v = sb[xb + ivoff + sx: xb + ivoff + sx + 32].view(np.float32).astype(np.float64)
+                            ildso = r * 64 + ((q ^ ((r >> 1) & 3)) << 4)
+                            for pl, part in enumerate((np.round(v * 4) / 4, v - np.round(v * 4) / 4, np.zeros(8))):
+                                assert (pl, ildso) not in xpl
+                                xpl[pl, ildso] = part
             for wave in range(NW):
                 wm, wn = wave % WM, wave // WM
                 for lane in range(64):
@@ -68,7 +91,7 @@ def main(WM, WN, RB, ntok, scenes_total, tail=0):
                     wf = np.zeros((4, 3, 8), np.float64)
                     for j in range(4):
                         nr = wn * 64 + j * 16 + l15
-                        woff = A_STAGE + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4)
+                        woff = XA + nr * 64 + ((g ^ ((nr >> 1) & 3)) << 4)
                         for pl in range(3):
                             wf[j, pl] = lds[woff + pl * B_PLANE: woff + pl * B_PLANE + 16].view(np.int16)
                     acc_lane_w = wf
@@ -76,7 +99,11 @@ def main(WM, WN, RB, ntok, scenes_total, tail=0):
                         r = (wm * RB + i) * 16 + l15
                         a0 = r * 128 + (((2 * g) ^ (r & 7)) << 4)
                         a1 = r * 128 + (((2 * g + 1) ^ (r & 7)) << 4)
-                        xf = np.concatenate([lds[a0:a0 + 16].view(np.float32), lds[a1:a1 + 16].view(np.float32)]).astype(np.float64)
+                        if pipe3:
+                            xo = r * 64 + ((g ^ ((r >> 1) & 3)) << 4)
+                            xf = xpl[0, xo] + xpl[1, xo] + xpl[2, xo]
+                        else:
+                            xf = np.concatenate([lds[a0:a0 + 16].view(np.float32), lds[a1:a1 + 16].view(np.float32)]).astype(np.float64)
                         # stash the fragments; the MFMA is evaluated below over all lanes of the wave
                         FR.setdefault((wave, i), np.zeros((64, 8)))[lane] = xf
                     FW[wave, lane] = acc_lane_w
@@ -112,8 +139,8 @@ def main(WM, WN, RB, ntok, scenes_total, tail=0):
     ref = xcat.astype(np.float64) @ planes.astype(np.float64).sum(axis=0).T
     assert written.all(), "some outputs were never stored"
     err = np.abs(out - ref).max()
-    print("waves %d x %d, RB %d, %d tokens/scene, %d scenes: max |emulated kernel - [x | x2].w^T| = %.3e over %d x %d outputs (K = %d + %d)" % (
-        WM, WN, RB, ntok, scenes_total, err, M, N, K1, K - K1))
+    print("%swaves %d x %d, RB %d, %d tokens/scene, %d scenes: max |emulated kernel - [x | x2].w^T| = %.3e over %d x %d outputs (K = %d + %d)" % (
+        "PIPE 3 (staged planes) " if pipe3 else "", WM, WN, RB, ntok, scenes_total, err, M, N, K1, K - K1))
     assert err < 1e-9 * max(1.0, np.abs(ref).max())
     print("index arithmetic consistent")
 
@@ -154,3 +181,5 @@ if __name__ == "__main__":
     for cfg in ((2, 4, 5, 80, 4), (4, 2, 5, 80, 5), (4, 2, 2, 21, 7), (2, 4, 5, 80, 3), (2, 4, 5, 80, 4, 70)):
         main(*cfg)
         bank_check(*cfg[:3])
+    for cfg in ((2, 4, 5, 80, 4), (4, 2, 2, 21, 7), (2, 4, 5, 80, 4, 70)):
+        main(*cfg, **({"pipe3": True} if len(cfg) == 6 else {"tail": 0, "pipe3": True}))
