@@ -175,8 +175,80 @@ def bank_check(WM, WN, RB):
     assert worst == 1
 
 
+def tn_check():
+    """tools/gemm_tn_bf16x6.hip: staging items -> channel-major planes -> fragments -> MFMA (x as row operand) -> stores."""
+    BN_, BKO, COLS, T = 256, 128, 384, 512
+    rng = np.random.default_rng(1)
+    M, N, K, slices = 128, 256, 256, 2                      # 2 steps per slice; grid 1 x 2 x 2
+    ldy, ldx = N + 4, K + 12
+    dy = rng.integers(-8, 8, size=(M, ldy)).astype(np.float64)
+    x = rng.integers(-8, 8, size=(M, ldx)).astype(np.float64)
+    rows_per_slice = M // slices
+    out = np.zeros((slices, N, K))
+    written = np.zeros((slices, N, K), bool)
+    for bx in range(N // BN_):
+        for by in range(K // BKO):
+            for sl in range(slices):
+                n0, k0, m_begin = bx * BN_, by * BKO, sl * rows_per_slice
+                acc = np.zeros((8, 4, 4, 64, 4))
+                for step in range(rows_per_slice // 32):
+                    mb = m_begin + step * 32
+                    planes = {}
+                    for u in range(3):
+                        for tid in range(T):
+                            wave = tid >> 6
+                            t = u * T + tid
+                            c, og = t % COLS, t // COLS
+                            isdy = ((u * T + wave * 64) % COLS) < BN_
+                            assert isdy == (c < BN_)        # the wave-uniform test agrees with every lane of the wave
+                            if isdy:
+                                v = np.array([dy[mb + 8 * og + e, n0 + c] for e in range(8)])
+                            else:
+                                v = np.array([x[mb + 8 * og + e, k0 + c - BN_] for e in range(8)])
+                            ildso = c * 64 + ((og ^ ((c >> 1) & 3)) << 4)
+                            assert ildso not in planes
+                            planes[ildso] = v
+                    for wave in range(8):
+                        wn, wk = wave & 3, wave >> 2
+                        xf = np.zeros((4, 64, 8)); df = np.zeros((4, 64, 8))
+                        for lane in range(64):
+                            g, l15 = lane >> 4, lane & 15
+                            for b in range(4):
+                                cx, cd = BN_ + wk * 64 + b * 16 + l15, wn * 64 + b * 16 + l15
+                                xf[b, lane] = planes[cx * 64 + ((g ^ ((cx >> 1) & 3)) << 4)]
+                                df[b, lane] = planes[cd * 64 + ((g ^ ((cd >> 1) & 3)) << 4)]
+                        for kb in range(4):
+                            for nb in range(4):
+                                A = np.zeros((16, 32)); B = np.zeros((32, 16))
+                                for lane in range(64):
+                                    g, l15 = lane >> 4, lane & 15
+                                    A[l15, 8 * g: 8 * g + 8] = xf[kb, lane]          # row operand: x channel (k)
+                                    B[8 * g: 8 * g + 8, l15] = df[nb, lane]          # column operand: dy channel (n)
+                                D = A @ B
+                                for lane in range(64):
+                                    g, l15 = lane >> 4, lane & 15
+                                    acc[wave, kb, nb, lane] += D[4 * g: 4 * g + 4, l15]
+                for wave in range(8):
+                    wn, wk = wave & 3, wave >> 2
+                    for lane in range(64):
+                        g, l15 = lane >> 4, lane & 15
+                        for nb in range(4):
+                            for kb in range(4):
+                                n = n0 + wn * 64 + l15 + nb * 16
+                                k = k0 + wk * 64 + 4 * g + kb * 16
+                                assert not written[sl, n, k]
+                                written[sl, n, k: k + 4] = True
+                                out[sl, n, k: k + 4] = acc[wave, kb, nb, lane]
+    ref = dy[:, :N].T @ x[:, :K]
+    err = np.abs(out.sum(axis=0) - ref).max()
+    assert written.all()
+    print("TN: max |emulated kernel - dy^T.x| = %.3e over %d x %d outputs (%d tokens in %d slices)" % (err, N, K, M, slices))
+    assert err == 0
+
+
 FR, FW = {}, {}
 if __name__ == "__main__":
+    tn_check()
     # (WM, WN, RB, tokens per scene, scenes): the 80-token tiles, a ragged scene count, 21-token scenes, a dense GEMM with a row tail
     for cfg in ((2, 4, 5, 80, 4), (4, 2, 5, 80, 5), (4, 2, 2, 21, 7), (2, 4, 5, 80, 3), (2, 4, 5, 80, 4, 70)):
         main(*cfg)

@@ -26,6 +26,7 @@ pmc) cd /tmp && export TMPDIR=/tmp
   python tools/pmc_summary.py $TAG > $O/${TAG}_pmc_summary.json 2>&1; tail -25 $O/${TAG}_pmc_summary.json ;;
 bf16x6) timeout 300 python tools/gemm_bf16x6.py > $O/${TAG}_gemm_bf16x6.txt 2>&1; tail -30 $O/${TAG}_gemm_bf16x6.txt
   timeout 300 python tools/gemm_bf16x6.py --noslp --k 512 > $O/${TAG}_gemm_bf16x6_noslp.txt 2>&1; tail -12 $O/${TAG}_gemm_bf16x6_noslp.txt ;;
+bf16x6tn) timeout 300 python tools/gemm_tn_bf16x6.py > $O/${TAG}_gemm_tn_bf16x6.txt 2>&1; tail -24 $O/${TAG}_gemm_tn_bf16x6.txt ;;
 *) echo "unknown step $s" ;;
 esac
 done
