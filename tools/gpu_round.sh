@@ -24,8 +24,9 @@ pmc) cd /tmp && export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o w -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_write.log 2>&1
   cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_pmc_sample -name "*.db" | head -1) > $O/${TAG}_sample_pmc.txt 2>&1
   python tools/pmc_summary.py $TAG > $O/${TAG}_pmc_summary.json 2>&1; tail -25 $O/${TAG}_pmc_summary.json ;;
-bf16x6) timeout 300 python tools/gemm_bf16x6.py > $O/${TAG}_gemm_bf16x6.txt 2>&1; tail -30 $O/${TAG}_gemm_bf16x6.txt
-  timeout 300 python tools/gemm_bf16x6.py --noslp --k 512 > $O/${TAG}_gemm_bf16x6_noslp.txt 2>&1; tail -12 $O/${TAG}_gemm_bf16x6_noslp.txt ;;
+bf16x6) for v in 6:1 6:3 6:2 6:0; do timeout 200 python tools/gemm_bf16x6.py --k 512 --variants $v --no-extras > $O/${TAG}_gemm_bf16x6_v${v/:/_}.txt 2>&1; tail -8 $O/${TAG}_gemm_bf16x6_v${v/:/_}.txt; done
+  timeout 400 python tools/gemm_bf16x6.py > $O/${TAG}_gemm_bf16x6.txt 2>&1; tail -40 $O/${TAG}_gemm_bf16x6.txt
+  timeout 300 python tools/gemm_bf16x6.py --noslp --k 512 --no-extras > $O/${TAG}_gemm_bf16x6_noslp.txt 2>&1; tail -12 $O/${TAG}_gemm_bf16x6_noslp.txt ;;
 bf16x6tn) timeout 300 python tools/gemm_tn_bf16x6.py > $O/${TAG}_gemm_tn_bf16x6.txt 2>&1; tail -24 $O/${TAG}_gemm_tn_bf16x6.txt ;;
 *) echo "unknown step $s" ;;
 esac
