@@ -101,7 +101,10 @@ struct Args {
     int ntok;                // tokens per scene (<= 16*RB); dense GEMM: 16*RB
     // GroupNorm(8 groups of 64 channels over the ntok tokens of a scene) + (scale + 1, shift) + SiLU (+ residual) epilogue
     const float* gamma; const float* beta; float eps;
-    const float* scale_shift; int ld_ss;   // per scene: [scale(n) | shift(n)], or null
+    const float* scale_shift; int ld_ss;   // rows [scale(n) | shift(n)], or null
+    int ss_mode;                           // the product's DSC_SS_*: 0 none, 1 row = token, 2 row = scene, 3 row = token % ntok, 4 row = ss_index[scene]
+    const int64_t* ss_index;               // mode 4: per scene (the timestep vector while sampling)
+    float* preact; int ld_pre;             // optional: z = x.w^T + bias saved for the backward
     const float* residual; int ldr;        // or null (added after the activation)
     int act;                               // plain epilogue: 0 none, 1 GELU (erf), 2 SiLU
 };
@@ -496,20 +499,32 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
         // The wave tile IS one GroupNorm cell: the ntok tokens of scene (row0 / ntok + wm) x the 64 channels of group
         // (col0 / 64 + wn).  Statistics are wave-local (two passes over the lane's accumulators + a wave sum; padding rows
         // masked): no LDS, no block barrier.
-        const int scene = row0 / p.ntok + wm;
+        const int scene = min(row0 / p.ntok + wm, p.m / p.ntok - 1);
+        const bool per_row = p.ss_mode == 1 || p.ss_mode == 3;       // scale/shift differ per token: applied per element below
         f32x4 ga[4], be[4], sc[4], sh[4];
+        int64_t ssrow = scene;
+        if (p.ss_mode == 4) ssrow = p.ss_index[scene];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                    // issued first: their latency hides under the statistics
             ga[j] = *(const f32x4*)(p.gamma + cbase + j * 16);
             be[j] = *(const f32x4*)(p.beta + cbase + j * 16);
-            if (p.scale_shift) {
-                const float* ssr = p.scale_shift + (int64_t)min(scene, p.m / p.ntok - 1) * p.ld_ss + cbase + j * 16;
+            if (p.ss_mode == 2 || p.ss_mode == 4) {
+                const float* ssr = p.scale_shift + ssrow * p.ld_ss + cbase + j * 16;
                 sc[j] = *(const f32x4*)ssr;
                 sh[j] = *(const f32x4*)(ssr + p.n);
             } else {
                 sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 sh[j] = sc[j];
             }
+        }
+        if (p.preact) {
+            float* const pb = p.preact + (int64_t)(row0 + srow + l15) * p.ld_pre + cbase;
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if (valid[i]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *(f32x4*)(pb + (int64_t)i * 16 * p.ld_pre + j * 16) = acc[i][j];
+                }
         }
         auto wave_sum = [](float v) {
 #pragma unroll
@@ -548,10 +563,17 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             if (valid[i]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f32x4 y;
+                    f32x4 y, s1 = {1.f, 1.f, 1.f, 1.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+                    if (per_row) {
+                        const int64_t row = p.ss_mode == 1 ? (int64_t)row0 + srow + i * 16 + l15 : (int64_t)i * 16 + l15;
+                        const float* ssr = p.scale_shift + row * p.ld_ss + cbase + j * 16;
+                        s1 = *(const f32x4*)ssr + 1.f;
+                        s2 = *(const f32x4*)(ssr + p.n);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float t = fmaf(acc[i][j][e], ga[j][e], be[j][e]);
+                        float t = fmaf(acc[i][j][e], ga[j][e], be[j][e]);
+                        if (per_row) t = fmaf(t, s1[e], s2[e]);
                         y[e] = t / (1.f + __expf(-t));
                     }
                     if (rbp) y += *(const f32x4*)(rbp + (int64_t)i * 16 * p.ldr + j * 16);
@@ -603,13 +625,16 @@ int bf16x6_split_planes(const float* w, long count, uint16_t* planes, hipStream_
 // fused epilogue (80 -> RB 5; <= 32, e.g. 21 -> RB 2 with 4 scenes x 128 channels per block); 0 = dense rows (plain GEMM, RB 5).
 int bf16x6_launch(const float* x, const float* x2, int k1, int lda, const uint16_t* planes, const float* bias, float* out, int ldc,
                   int m, int n, int k, int act, const float* residual, int ldr, int gn, const float* gamma, const float* beta,
-                  float eps, const float* scale_shift, int ld_ss, int ntok, int products, int pipe, int tile, hipStream_t s) {
+                  float eps, const float* scale_shift, int ld_ss, int ss_mode, const int64_t* ss_index, float* preact, int ld_pre, int ntok,
+                  int products, int pipe, int tile, hipStream_t s) {
     if (k % BK || k1 % BK || k1 <= 0 || k1 > k || (k1 < k && !x2) || (lda & 3) || (ldc & 3) || (ldr & 3) || (ld_ss & 3) || m <= 0)
         return 2;
-    if (gn && (ntok <= 0 || !gamma || !beta)) return 2;
+    if (gn && (ntok <= 0 || !gamma || !beta || ss_mode < 0 || ss_mode > 4 || (ss_mode && !scale_shift) || (ss_mode == 4 && !ss_index) ||
+               (ld_pre & 3)))
+        return 2;
     const bool small = ntok > 0 && ntok <= 32;
     Args a{x, k1 < k ? x2 : nullptr, k1, planes, bias, out, m, n, k, lda, ldc, small ? ntok : (ntok > 0 ? ntok : 80),
-           gamma, beta, eps, scale_shift, ld_ss, residual, ldr, act};
+           gamma, beta, eps, scale_shift, ld_ss, scale_shift ? ss_mode : 0, ss_index, preact, ld_pre, residual, ldr, act};
     if (small) return launch_cfg<4, 2, 2>(a, gn, products, pipe, s);
     if (tile == 1 || (tile == 0 && n % 256 == 0)) return launch_cfg<2, 4, 5>(a, gn, products, pipe, s);
     return launch_cfg<4, 2, 5>(a, gn, products, pipe, s);

@@ -45,17 +45,19 @@ def main():
     lib.bf16x6_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,   # x x2 k1 lda planes bias out ldc
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,                                # m n k act residual ldr
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,                        # gn gamma beta eps ss ld_ss
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_int,                                               # ss_mode ss_index preact ld_pre
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]                                         # ntok products pipe tile stream
 
     def ptr(t):
         return t.data_ptr() if t is not None else None
 
     def launch6(xin, planes_t, bias, out, m, n, k, products, pipe, x2=None, k1=None, act=0, residual=None, gn=None, tile=0, stream=None,
-                ntok=0):
+                ntok=0, ss_mode=2, ss_index=None, preact=None):
         gamma, beta, ss = gn if gn is not None else (None, None, None)
         rc = lib.bf16x6_launch(ptr(xin), ptr(x2), k if k1 is None else k1, xin.stride(0), ptr(planes_t), ptr(bias), ptr(out), out.stride(0),
                                m, n, k, act, ptr(residual), residual.stride(0) if residual is not None else 0,
                                1 if gn is not None else 0, ptr(gamma), ptr(beta), 1e-5, ptr(ss), ss.stride(0) if ss is not None else 0,
+                               ss_mode if ss is not None else 0, ptr(ss_index), ptr(preact), preact.stride(0) if preact is not None else 0,
                                ntok if ntok else (80 if gn is not None else 0), products, pipe, tile, stream)
         assert rc == 0, ("bf16x6_launch", rc, products, pipe)
 
@@ -184,6 +186,23 @@ def main():
                 run_gn(pp)
                 torch.cuda.synchronize()
                 print("K=%d  GN  bf16 split x6 pipe=%d          max %.2e  rms %.2e" % ((K, pp) + err_gn(ygn[pp])), flush=True)
+            # the other conditioning modes of the product epilogue + the saved pre-activation, against dsc_gemm_gn_silu_f32
+            pp = gn_pipes[-1]
+            ss_slot = torch.randn(N, 2 * NOUT, device=dev) * 0.1                       # DSC_SS_PER_SLOT: row = token % N
+            ss_tab = torch.randn(1000, 2 * NOUT, device=dev) * 0.1                     # DSC_SS_BY_INDEX: row = t[scene]
+            tvec = torch.randint(0, 1000, (B,), device=dev, dtype=torch.int64)
+            ss_tok = torch.randn(M, 2 * NOUT, device=dev) * 0.1                        # DSC_SS_PER_TOKEN
+            for mode, sst, idx in ((3, ss_slot, None), (4, ss_tab, tvec), (1, ss_tok, None)):
+                ya, yb = torch.empty(M, NOUT, device=dev), torch.zeros(M, NOUT, device=dev)
+                pa, pb = torch.empty(M, NOUT, device=dev), torch.zeros(M, NOUT, device=dev)
+                gm = ops.make_gemm_args(x, w, ya, b, None, res, gamma=gamma, beta=beta, tokens_per_scene=N, scale_shift=sst, ss_mode=mode,
+                                        preact=pa, ss_index=idx)
+                ops.run_gemm(gm, gn=True)
+                launch6(x, planes, b, yb, M, NOUT, K, 6, pp, residual=res, gn=(gamma, beta, sst), stream=s, ss_mode=mode, ss_index=idx, preact=pb)
+                torch.cuda.synchronize()
+                print("K=%d  GN  ss_mode=%d pipe=%d vs dsc_gemm_gn_silu_f32: max |diff| / rms = %.2e, preact %.2e" % (
+                    K, mode, pp, float((ya - yb).abs().max()) / float(ya.pow(2).mean().sqrt()),
+                    float((pa - pb).abs().max()) / float(pa.pow(2).mean().sqrt())), flush=True)
             names = ["prod"] + gn_pipes
             for _ in range(150):
                 ops.run_gemm(ggn, gn=True)
