@@ -16,11 +16,16 @@
 // Layout: 8 waves as WM x WN; a wave owns ONE scene (ntok <= 16*RB tokens, padded to RB MFMA row blocks inside LDS) x 64
 // channels = RB x 4 MFMA blocks of 16 x 16 -- exactly one GroupNorm cell.  RB = 5: 80-token scenes, block 160 tokens x 256
 // channels (M = 20480, n = 512 -> 256 blocks = one round of 256 CUs) or 320 x 128; RB = 2: scenes of <= 32 tokens (N = 21:
-// 4 scenes x 128 channels per block -> 256 blocks at B = 256).  Plain GEMMs use ntok = 16*RB (dense).  BK = 32 = one MFMA k-step.  x stays f32 in LDS (20 KiB / stage), the weights
-// are pre-split into three bf16 planes [3][n][k] by split_planes_kernel (once per weight update) and staged as planes
-// (48 KiB / stage); two stages, both filled by LDS-DMA (lane-linear image, XOR swizzles applied on the global side).
+// 4 scenes x 128 channels per block -> 256 blocks at B = 256).  Plain GEMMs use ntok = 16*RB (dense).  BK = 32 = one MFMA
+// k-step.  The weights are pre-split into three bf16 planes [3][n][k] by split_planes_kernel (once per weight update) and
+// staged as planes by LDS-DMA (lane-linear image, XOR swizzle applied on the global side).  The tokens, per main-loop form:
+//   PIPE 0-2: x stays f32 in LDS (LDS-DMA as well) and every wave splits its fragments after the LDS read -- compiler-
+//             scheduled (0), split of block i+1 slotted between the MFMAs of block i inside a K tile (1), or across tiles (2);
+//   PIPE 3:   the staging threads load f32 rows into registers, split ONCE per block under the previous tile's MFMAs and write
+//             three bf16 planes to LDS (no wave repeats the split of rows it shares; fragments are three 16-byte reads).
 // The MFMA computes out^T (weights as the row operand) so that each lane holds 4 consecutive channels of one token: the
-// plain epilogue is one 16-byte store per accumulator.
+// plain epilogue is one 16-byte store per accumulator; the fused Block epilogue (all conditioning modes of the product's
+// dsc_gemm_gn_silu_f32, optional saved pre-activation) needs no LDS and no block barrier.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
