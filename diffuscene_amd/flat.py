@@ -103,6 +103,14 @@ class FlatStorage:
             object.__setattr__(net, "_flat", self)
         object.__setattr__(module, "_dsc_flat", self)
 
+    # copy.deepcopy(model) (an EMA copy) / pickling must not drag the flat buffers, the ctypes argument tables or the captured
+    # graphs along: the copy gets no flat storage and builds its own on its first training step (ensure_flat)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def attach_grads(self):
         """(Re-)point every ``p.grad`` at its slice of G (``optimizer.zero_grad(set_to_none=True)`` drops them)."""
         for p in self.params:

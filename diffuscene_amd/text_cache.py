@@ -39,6 +39,14 @@ class BertFeatureCache:
         self.model.eval()
         for i in range(0, len(todo), batch_size):
             chunk = todo[i:i + batch_size]
+            # the reference's tokenizer(text, padding=True) never truncates: a description longer than max_tokens would silently
+            # get different features here, so it is an error (build the cache with a larger max_tokens)
+            full = self.tokenizer(chunk, padding=False, truncation=False)["input_ids"]
+            too_long = [(t, len(ids)) for t, ids in zip(chunk, full) if len(ids) > self.max_tokens]
+            if too_long:
+                raise ValueError("BertFeatureCache(max_tokens=%d): %d description(s) tokenize longer (longest %d tokens: %r); "
+                                 "the reference does not truncate" % (self.max_tokens, len(too_long),
+                                                                      max(n for _, n in too_long), too_long[0][0][:80]))
             tok = self.tokenizer(chunk, return_tensors="pt", padding="max_length", truncation=True, max_length=self.max_tokens)
             n_tok = tok["attention_mask"].sum(dim=1).tolist()
             out = self.model(**{k: v.to(dev) for k, v in tok.items()}).last_hidden_state.to(self.store)

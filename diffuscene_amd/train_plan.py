@@ -370,6 +370,7 @@ class TrainPlan:
         self._tn_pending = []             # deferred weight-gradient GEMMs (leaves of the backward): one grouped launch
         self._cs_pending = []             # deferred column sums of per-scene gradient partials: one grouped launch
         self.n_adds = 0
+        self.bytes = 0                    # statically allocated activation / gradient bytes (the runner's cache budget)
         C_in = net.channels
         dev = self.device
         # ---- static inputs
@@ -402,12 +403,15 @@ class TrainPlan:
 
     # ------------------------------------------------------------------------------------------------ buffers
     def new(self, rows, cols):
+        self.bytes += 4 * rows * cols
         return torch.empty((rows, cols), device=self.device, dtype=torch.float32)
 
     def new3(self, a, b, c):
+        self.bytes += 4 * a * b * c
         return torch.empty((a, b, c), device=self.device, dtype=torch.float32)
 
     def zeros(self, rows, cols):
+        self.bytes += 4 * rows * cols
         return torch.zeros((rows, cols), device=self.device, dtype=torch.float32)
 
     def emit(self, step):
@@ -1036,6 +1040,10 @@ class TrainPlan:
         for i in range(len(self.bwd)):
             self.be.run(self.bwd[i:i + 1], s)
             on_progress(i)
+
+    def run_backward_range(self, lo, hi):
+        """Launches lo .. hi-1 of the backward list (one captured segment of the data-parallel step)."""
+        self.be.run(self.bwd[lo:hi], self.stream())
 
     def bucket_schedule(self, buckets):
         """For contiguous G ranges [(start, end)]: {launch index: [bucket ids finished by that launch]}; buckets nothing

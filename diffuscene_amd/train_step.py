@@ -7,7 +7,8 @@ is ONE hipGraph replay on a single GPU:
     host: build target / conditioning (reference :131-226), draw t and the noise in the reference's RNG order
     graph: q_sample -> Unet1D forward -> p_losses (+ d loss / d out) -> backward of every layer -> gradients in flat G
     host: (only for conditioning computed by torch modules: fc_text_f, fc_arrange_condition ...) autograd through them
-    data parallel: buckets of G are all-reduced over RCCL as the backward finishes them (no graph; launches are eager)
+    data parallel: the same launch list cut into a few hipGraph SEGMENTS at the launches that finish a bucket of G; the bucket
+        all-reduces (RCCL) are issued between the segment replays and run beside the rest of the backward
     FusedAdam: gradient norm + clip coefficient + Adam sweep on the device; one device->host copy for the logged scalars
 """
 import os
@@ -32,6 +33,8 @@ def plan_supported(model):
         return False
     if d.loss_type != 'mse' or d.translation_dim != 3 or model.sample_num_points > 160:
         return False
+    if not all(q.requires_grad for q in net.parameters()):
+        return False                    # a frozen denoiser parameter has no slice of G: autograd path
     full = model.bbox_dim + model.class_dim + model.objectness_dim + model.objfeat_dim
     if model.room_arrange_condition:
         return net.channels == model.translation_dim + model.angle_dim
@@ -44,8 +47,15 @@ class PlanRunner:
     def __init__(self, model):
         self.model = model
         self.flat = ensure_flat(model)
-        self.plans = {}
+        self.plans = {}                   # insertion-ordered: least recently used first
+        self.last_key = None
         self.synced = False
+
+    def __deepcopy__(self, memo):         # plans hold ctypes tables and captured graphs: a copied model builds its own
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     def world(self):
         import torch.distributed as dist
@@ -58,24 +68,46 @@ class PlanRunner:
             return False
         return dist.get_world_size() > 1 or os.environ.get("DSC_DDP_FORCE", "0") == "1"
 
+    def budget_bytes(self):
+        """Activation memory all cached plans together may hold (a plan owns every activation and gradient of its signature:
+        ~20 GB at B=256, N=80; tens of MB for a small last batch)."""
+        if self.flat.device.type != "cuda":
+            return 1 << 62
+        total = torch.cuda.get_device_properties(self.flat.device).total_memory
+        return int(float(os.environ.get("DSC_PLAN_CACHE_FRAC", "0.35")) * total)
+
     def plan_for(self, B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param):
         from .train_plan import HipBackend, TrainPlan
         ws = self.world()
-        key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, self.distributed())
-        ent = self.plans.get(key)
+        distributed = self.distributed()
+        # data parallel: "block" flushes the weight gradients every few ResnetBlocks so that buckets of G leave early,
+        # "end" keeps the single-GPU schedule (fewer, larger grouped launches; the exchange overlaps less)
+        per_block = distributed and os.environ.get("DSC_DDP_FLUSH", "block") == "block"
+        key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block)
+        ent = self.plans.pop(key, None)
         if ent is None:
             model = self.model
             dev = self.flat.device
+            # least recently used signatures go first (text batches change L, the last batch of an epoch changes B);
+            # at least the two most recent ones stay
+            budget = self.budget_bytes()
+            while self.plans and (len(self.plans) >= int(os.environ.get("DSC_PLAN_CACHE_MAX", "16")) or
+                                  (len(self.plans) >= 2 and sum(e["plan"].bytes for e in self.plans.values()) > budget)):
+                self.plans.pop(next(iter(self.plans)))
             plan = TrainPlan(model.diffusion.model, self.flat, model.diffusion.diffusion, B, N, ctx_mode, ctx_dim, L,
-                             text_dim, HipBackend(dev), per_block_grads=self.distributed(), ctx_param=ctx_param,
+                             text_dim, HipBackend(dev), per_block_grads=per_block, ctx_param=ctx_param,
                              grad_scale=1.0 / (B * ws))
             ent = {"plan": plan, "graph": None, "reducer": None, "warm": 0}
-            if self.distributed():
+            if distributed:
                 from .ddp import FlatGradientReducer
                 ent["reducer"] = FlatGradientReducer(self.flat, plan)
-            while len(self.plans) >= 3:             # a plan owns all its activations (~20 GB at B=256, N=80): keep a few
-                self.plans.pop(next(iter(self.plans)))
-            self.plans[key] = ent
+        self.plans[key] = ent                       # (re-)inserted last = most recently used
+        if key != self.last_key:
+            # parameters the previous signature wrote but this one never touches (cross-attention without text, ...) must not
+            # keep a stale gradient for Adam: the reference leaves those .grad None
+            if self.last_key is not None:
+                self.flat.G.zero_()
+            self.last_key = key
         return ent
 
     def run(self, ent, backward):
@@ -83,29 +115,87 @@ class PlanRunner:
         if not backward:
             plan.run_forward()
             return
-        if ent["reducer"] is not None:
+        red = ent["reducer"]
+        eager = os.environ.get("DSC_TRAIN_GRAPH", "1") == "0"
+        if ent["graph"] is None and not eager and ent["warm"] >= 1:
+            ent["graph"] = _capture(plan, red, self.flat.device)
+            if ent["graph"] is None:
+                eager = ent["eager_only"] = True
+        if eager or ent.get("eager_only") or ent["graph"] is None:
+            # first step (and DSC_TRAIN_GRAPH=0) eagerly: loads every code object, surfaces launch errors with a Python stack
+            ent["warm"] += 1
             plan.run_forward()
-            plan.run_backward(on_progress=ent["reducer"].on_progress)
+            plan.run_backward(on_progress=red.on_progress if red is not None else None)
             return
-        if os.environ.get("DSC_TRAIN_GRAPH", "1") == "0":
-            plan.run_forward()
-            plan.run_backward()
-            return
-        if ent["graph"] is None:
-            if ent["warm"] < 1:
-                # first step eagerly: loads every code object and surfaces launch errors with a Python stack
-                ent["warm"] += 1
-                plan.run_forward()
-                plan.run_backward()
-                return
-            dev = self.flat.device
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                plan.run_forward()
-                plan.run_backward()
-            ent["graph"] = g
-            torch.cuda.current_stream(dev).synchronize()
         ent["graph"].replay()
+
+
+class _StepGraphs:
+    """The captured training step.  Single GPU: ONE hipGraph (forward + loss + backward).  Data parallel: the same launch list
+    cut after every launch that completes a gradient bucket -- segment 0 = forward + loss + backward up to the first cut -- each
+    segment its own hipGraph; after replaying a segment the reducer issues the all-reduce of the buckets it finished (eager RCCL
+    launches on the collective stream, ordered behind the segment by an event), so the exchange runs beside the remaining
+    segments and no collective is ever inside a graph."""
+
+    def __init__(self, plan, reducer):
+        self.plan, self.reducer = plan, reducer
+        cuts = sorted(reducer.at_launch) if reducer is not None else []
+        self.segments, lo = [], 0                     # (first backward launch, one past the last, cut index or None)
+        for c in cuts:
+            self.segments.append((lo, c + 1, c))
+            lo = c + 1
+        if lo < len(plan.bwd) or not self.segments:
+            self.segments.append((lo, len(plan.bwd), None))
+        self.graphs = []
+
+    def capture(self, make_graph):
+        for i, (lo, hi, _) in enumerate(self.segments):
+            def body(i=i, lo=lo, hi=hi):
+                if i == 0:
+                    self.plan.run_forward()
+                self.plan.run_backward_range(lo, hi)
+            self.graphs.append(make_graph(body))
+
+    def replay(self):
+        for g, (_, _, cut) in zip(self.graphs, self.segments):
+            g.replay()
+            if cut is not None:
+                self.reducer.on_progress(cut)
+
+
+class _EagerSegment:
+    """Stand-in for a captured segment on devices without graphs (the CPU plan backend of the tests)."""
+
+    def __init__(self, body):
+        self.body = body
+
+    def replay(self):
+        self.body()
+
+
+def _capture(plan, reducer, device):
+    """-> _StepGraphs, or None when the capture failed (the step then stays eager: same launches, same results)."""
+    sg = _StepGraphs(plan, reducer)
+    if device.type != "cuda":
+        sg.capture(_EagerSegment)
+        return sg
+
+    def make(body):
+        g = torch.cuda.CUDAGraph()
+        # thread_local: CUDA calls of other host threads (a DataLoader's pin-memory thread) do not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            body()
+        return g
+    try:
+        sg.capture(make)
+    except Exception as e:                                  # noqa: BLE001 -- any capture failure: keep training eagerly
+        import warnings
+        warnings.warn("diffuscene_amd: hipGraph capture of the training step failed (%s: %s); running it eagerly"
+                      % (type(e).__name__, e))
+        torch.cuda.synchronize(device)
+        return None
+    torch.cuda.current_stream(device).synchronize()
+    return sg
 
 
 def _runner(model):

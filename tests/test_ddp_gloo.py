@@ -159,6 +159,18 @@ def _plan_worker(rank, ws, port, tmp):
     assert n == len(red.buckets) >= 8
     assert red.launched_during_backward >= 5, red.launched_during_backward     # overlapped with the backward
     assert torch.isfinite(flat.G).all()
+    # the captured form of the same step (train_step._StepGraphs): the launch list cut into segments at the launches that finish a
+    # bucket, the reducer called between segment replays -- same buckets in the same order, same reduced gradients
+    from diffuscene_amd.train_step import _capture
+    g_eager, order_eager = flat.G.clone(), list(red.last_order)
+    for p in flat.params:
+        flat.grad_view(p).fill_(float("nan"))
+    sg = _capture(plan, red, torch.device("cpu"))
+    assert len(sg.segments) >= 5 and sg.segments[0][0] == 0 and sg.segments[-1][1] == len(plan.bwd)
+    assert all(a[1] == b[0] for a, b in zip(sg.segments, sg.segments[1:]))          # contiguous, nothing skipped or repeated
+    sg.replay()
+    assert red.finish() == n and red.last_order == order_eager
+    assert torch.equal(flat.G, g_eager)
     if rank == 0:
         torch.save({"G": flat.G.clone(), "P": flat.P.clone(), "order": red.last_order,
                     "losses": plan.losses.clone()}, os.path.join(tmp, "plan_r0.pt"))

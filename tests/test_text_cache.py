@@ -37,3 +37,13 @@ def test_cached_features_equal_the_per_batch_encoder_call(tmp_path):
     assert torch.equal(c2.batch(sub, "cpu"), got2)
     sp = cache.attach_to_samples({"description": sub, "class_labels": torch.zeros(2, 3, 4)})
     assert torch.equal(sp["desc_bert"], got2)
+
+
+def test_truncation_is_an_error_not_a_silent_difference(tmp_path):
+    import pytest
+    from diffuscene_amd.text_cache import BertFeatureCache
+    tok, model = _tiny_bert(tmp_path)
+    cache = BertFeatureCache(tok, model, max_tokens=6)
+    cache.batch(["two nightstands"], "cpu")                                # 4 tokens with [CLS] / [SEP]: fits
+    with pytest.raises(ValueError, match="does not truncate"):
+        cache.batch(["there is a desk and a chair next to the bed"], "cpu")

@@ -39,6 +39,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 32, NW = 8, T = NW * 64;
+#ifdef RES_WARM
+constexpr int WARM_TILES = 4;
+#endif
 // A block is WM x WN waves of 80 tokens x 64 channels (8 waves): 2 x 4 -> 160 x 256 (one round at M = 20480, n = 512),
 // 4 x 2 -> 320 x 128 (n = 384 / 128 and other multiples of 128).
 template <int WM, int WN, int RB>
@@ -434,6 +437,25 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
             const int kn = min(kt + 1, KT - 1);              // the tail re-stages the last tile (no branch in the loop)
             dma_tile(kn, nxt);
             load_items(kn);
+#ifdef RES_WARM
+            // pull the residual tile (BM rows x BN f32 = 128-byte lines) towards L2 / MALL under the K loop: one dead 4-byte load per
+            // line, a few lines per thread, spread over the first K tiles -- the epilogue's residual read then no longer joins the
+            // HBM burst of the output stores
+            if (p.residual && kt < WARM_TILES) {
+                constexpr int LINES = BM * (BN * 4 / 128);                    // lines of the block's residual tile
+                constexpr int PER_T = (LINES + T * WARM_TILES - 1) / (T * WARM_TILES);
+#pragma unroll
+                for (int u = 0; u < PER_T; ++u) {
+                    const int ln = (kt * PER_T + u) * T + tid;
+                    const int r = ln / (BN * 4 / 128), c = ln % (BN * 4 / 128);
+                    const int sc = r / (16 * RB), tk = r % (16 * RB), gr = sc * p.ntok + tk;
+                    if (ln < LINES && tk < p.ntok && gr < rows_here) {
+                        float dead;
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(dead) : "v"(p.residual + (int64_t)(row0 + gr) * p.ldr + col0 + c * 32));
+                    }
+                }
+            }
+#endif
             bf16x8 wf[4][3], xf[2][3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *(const bf16x8*)(cur + pl * X_PLANE + xoff[0]);
@@ -522,6 +544,16 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                 sh[j] = sc[j];
             }
         }
+#ifdef RES_EARLY
+        f32x4 res[RB][4];
+        if (rbp) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    res[i][j] = valid[i] ? *(const f32x4*)(rbp + (int64_t)i * 16 * p.ldr + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#endif
         if (p.preact) {
             float* const pb = p.preact + (int64_t)(row0 + srow + l15) * p.ld_pre + cbase;
 #pragma unroll
@@ -581,7 +613,11 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                         if (per_row) t = fmaf(t, s1[e], s2[e]);
                         y[e] = t / (1.f + __expf(-t));
                     }
+#ifdef RES_EARLY
+                    if (rbp) y += res[i][j];
+#else
                     if (rbp) y += *(const f32x4*)(rbp + (int64_t)i * 16 * p.ldr + j * 16);
+#endif
                     *(f32x4*)(ob + (int64_t)i * 16 * p.ldc + j * 16) = y;
                 }
             }

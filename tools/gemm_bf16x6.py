@@ -19,7 +19,9 @@ SO_NOSLP = os.path.join(ROOT, "tools", "libgemm_bf16x6_noslp.so")   # scalar f32
 
 
 def build():
-    for so, extra in ((SO, []), (SO_NOSLP, ["-fno-slp-vectorize"])):
+    variants = ((SO, []), (SO_NOSLP, ["-fno-slp-vectorize"]), (SO.replace(".so", "_researly.so"), ["-DRES_EARLY"]),
+                (SO.replace(".so", "_reswarm.so"), ["-DRES_WARM"]), (SO.replace(".so", "_resboth.so"), ["-DRES_WARM", "-DRES_EARLY"]))
+    for so, extra in variants:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra +
                               [os.path.join(ROOT, "tools", "gemm_bf16x6.hip"), "-o", so])
         print("built", so)
@@ -39,7 +41,8 @@ def main():
     import torch
     from diffuscene_amd import ops
 
-    lib = C.CDLL(SO_NOSLP if "--noslp" in sys.argv else SO)
+    lib = C.CDLL(opt("--so", SO_NOSLP if "--noslp" in sys.argv else SO))
+    print("so:", opt("--so", "default"))
     print("library:", "no-SLP build (scalar subtractions)" if "--noslp" in sys.argv else "default build (v_pk_add_f32 in the split)")
     lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
     lib.bf16x6_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,   # x x2 k1 lda planes bias out ldc
