@@ -44,7 +44,13 @@ class GemmArgs(C.Structure):
         ("scale_shift", C.c_void_p), ("ld_ss", C.c_int64), ("ss_mode", C.c_int32),
         ("preact", C.c_void_p), ("ld_preact", C.c_int64),
         ("ss_index", C.c_void_p),
+        ("w_planes", C.c_void_p),
     ]
+
+
+class SplitItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("ldw", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("planes", C.c_void_p),
+                ("transpose", C.c_int32)]
 
 
 class WsItem(C.Structure):
@@ -75,6 +81,7 @@ SIGNATURES = {
     "dsc_version": (C.c_int, []),
     "dsc_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_gn_silu_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "dsc_split_bf16x3_f32": (C.c_int, [C.POINTER(SplitItem), C.c_int32, C.c_void_p]),
     "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_splitk_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_linear_smallk_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64,

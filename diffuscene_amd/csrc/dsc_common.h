@@ -77,4 +77,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// gemm_split.hip: the split-bf16 fast path of dsc_gemm_f32 / dsc_gemm_gn_silu_f32 (takes the launch when args->w_planes is set and
+// the shape qualifies)
+#define DSC_SPLIT_NOT_TAKEN (-1000)
+int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s);
+
 static inline bool dsc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

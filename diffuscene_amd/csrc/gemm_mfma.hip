@@ -75,6 +75,8 @@ extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
     int rc = check_common(a);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = dsc_gemm_try_split(a, false, s);                // pre-split weight planes supplied: f32-accurate product on the bf16 pipe
+    if (rc != DSC_SPLIT_NOT_TAKEN) return rc;
     const bool wide = (a->n % 256) == 0;
     struct Cand { int bm, bn, id; };
     // ties go to the earlier candidate: 160 x 128 (2 blocks per CU) measured 1 % ahead of 160 x 256 at M = 20480
@@ -115,6 +117,8 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
         if (a->ss_mode == DSC_SS_BY_INDEX && !a->ss_index) return DSC_EINVAL;
     } else if (a->scale_shift) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = dsc_gemm_try_split(a, true, s);
+    if (rc != DSC_SPLIT_NOT_TAKEN) return rc;
     // scene-aligned tiles: a block holds floor(BM / N) whole scenes; padded rows are wasted MFMA work
     struct Cand { int bm, bn; };
     const Cand cands[5] = {{160, 128}, {160, 256}, {128, 128}, {96, 128}, {64, 64}};

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, MEAN_EPS, MEAN_V, MEAN_X0, SS_NONE, SS_PER_SCENE,  # noqa: F401
-                   SS_PER_SLOT, SS_PER_TOKEN, GemmArgs, WsItem)
+                   SS_PER_SLOT, SS_PER_TOKEN, GemmArgs, SplitItem, WsItem)
 
 
 def stream_ptr():
@@ -41,9 +41,10 @@ def as2d(w):
 
 def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
                    gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None,
-                   ss_index=None):
+                   ss_index=None, w_planes=None):
     """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
-    pointers only; the caller keeps the tensors alive."""
+    pointers only; the caller keeps the tensors alive.  ``w_planes``: the weight pre-split into bf16 planes (split_planes):
+    the product runs on the bf16 matrix cores with f32 accuracy where the kernel supports the shape."""
     g = GemmArgs()
     g.a1, g.lda1 = _mat(a, "a")
     g.k1 = a.shape[1]
@@ -75,7 +76,41 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         g.preact, g.ld_preact = _mat(preact, "preact")
     if ss_index is not None:
         g.ss_index = _dev(ss_index, "ss_index", torch.int64).data_ptr()
+    if w_planes is not None:
+        if w_planes.dtype != torch.int16 or tuple(w_planes.shape) != (3, g.n, g.k1 + g.k2) or not w_planes.is_contiguous():
+            raise RuntimeError("w_planes must be a contiguous int16 tensor of shape (3, %d, %d)" % (g.n, g.k1 + g.k2))
+        g.w_planes = w_planes.data_ptr()
     return g
+
+
+def planes_wanted(n, k):
+    """Shapes the split-bf16 GEMM path covers (gemm_split.hip): callers skip the plane copy for everything else."""
+    return n % 128 == 0 and k % 32 == 0 and 6 * n * k < 0x7fffffff
+
+
+def split_planes(items, stream=None):
+    """Exact 3-way bf16 split of f32 matrices (dsc_split_bf16x3_f32).  items: [(w2d, planes, transpose)] with ``planes`` an int16
+    tensor (3, rows, cols) -- or (3, cols, rows) when ``transpose`` -- or None (allocated).  Returns the planes tensors."""
+    out, batch = [], []
+    for w, planes, tr in items:
+        w2 = as2d(_dev(w, "w"))
+        ptr, ldw = _mat(w2, "w")
+        r, c = w2.shape
+        shape = (3, c, r) if tr else (3, r, c)
+        if planes is None:
+            planes = torch.empty(shape, device=w2.device, dtype=torch.int16)
+        elif tuple(planes.shape) != shape or planes.dtype != torch.int16 or not planes.is_contiguous():
+            raise RuntimeError("split_planes: planes must be contiguous int16 %s" % (shape,))
+        out.append(planes)
+        batch.append((ptr, ldw, r, c, planes.data_ptr(), 1 if tr else 0, w2, planes))
+    for i in range(0, len(batch), _lib.WS_MAX):
+        part = batch[i:i + _lib.WS_MAX]
+        arr = (SplitItem * len(part))()
+        for j, (ptr, ldw, r, c, pp, tr, _, _) in enumerate(part):
+            arr[j].w, arr[j].ldw, arr[j].rows, arr[j].cols, arr[j].planes, arr[j].transpose = ptr, ldw, r, c, pp, tr
+        _lib.check(_lib.fn("dsc_split_bf16x3_f32")(arr, len(part), stream if stream is not None else stream_ptr()),
+                   "dsc_split_bf16x3_f32")
+    return out
 
 
 def run_gemm(g, gn=False, stream=None):
@@ -83,22 +118,22 @@ def run_gemm(g, gn=False, stream=None):
     _lib.check(_lib.fn(name)(C.byref(g), stream if stream is not None else stream_ptr()), name)
 
 
-def gemm(a, w, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+def gemm(a, w, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None, w_planes=None):
     w2 = as2d(w)
     if out is None:
         out = torch.empty((a.shape[0], w2.shape[0]), device=a.device, dtype=torch.float32)
-    run_gemm(make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out))
+    run_gemm(make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out, w_planes=w_planes))
     return out
 
 
 def gemm_gn_silu(a, w_std, bias, gamma, beta, tokens_per_scene, a2=None, scale_shift=None, ss_mode=SS_NONE,
-                 residual=None, eps=1e-5, out=None, preact=None):
+                 residual=None, eps=1e-5, out=None, preact=None, w_planes=None, ss_index=None):
     w2 = as2d(w_std)
     if out is None:
         out = torch.empty((a.shape[0], w2.shape[0]), device=a.device, dtype=torch.float32)
     run_gemm(make_gemm_args(a, w_std, out, bias, a2, residual, gamma=gamma, beta=beta, eps=eps,
                             tokens_per_scene=tokens_per_scene, scale_shift=scale_shift, ss_mode=ss_mode,
-                            preact=preact), gn=True)
+                            preact=preact, w_planes=w_planes, ss_index=ss_index), gn=True)
     return out
 
 

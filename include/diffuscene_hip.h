@@ -72,9 +72,21 @@ typedef struct dsc_gemm_args {
     const float* scale_shift; int64_t ld_ss; int32_t ss_mode; /* row layout [scale(n) | shift(n)] */
     float* preact; int64_t ld_preact;            /* optional: pre-norm conv output z = [A1|A2].W^T + bias, saved for backward */
     const int64_t* ss_index;                     /* DSC_SS_BY_INDEX: device int64 per scene (the timestep vector t) */
+    /* ---- optional: W pre-split into three bf16 planes [3][n][k1+k2] by dsc_split_bf16x3_f32 (same values as w) ----
+     * When set (and batch == 1, n % 128 == 0, 16-byte aligned y / bias / residual), dsc_gemm_f32 and dsc_gemm_gn_silu_f32 compute
+     * the SAME f32 product on the bf16 matrix cores: both operands split exactly into 3 bf16 pieces, the 6 significant piece
+     * products accumulated in f32 (error vs f64 <= the exact-f32 MFMA path's, ~1.5x faster).  NULL, an unsupported shape, or
+     * DSC_GEMM=f32 in the environment: the exact-f32 MFMA kernel runs. */
+    const uint16_t* w_planes;
 } dsc_gemm_args;
 
 int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
+
+/* Exact 3-way bf16 split of f32 matrices (x = x1 + x2 + x3, round-to-nearest at each step) for dsc_gemm_args.w_planes:
+ *   planes[p][r][c], p = 0..2, each plane [rows][cols] bf16 (or [cols][rows] with transpose != 0: the planes of w^T, the weight
+ * operand of the input-gradient GEMM dA = dY . W).  Output columns % 8 == 0.  items: HOST array, at most DSC_WS_MAX per call. */
+typedef struct dsc_split_item { const float* w; int64_t ldw; int32_t rows, cols; uint16_t* planes; int32_t transpose; } dsc_split_item;
+int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream);
 
 /* Block.forward (denoise_net.py:167-176) as ONE kernel:
  *   Y = SiLU( GroupNorm8( [A1|A2].W^T + bias ) * (scale + 1) + shift ) (+ residual)

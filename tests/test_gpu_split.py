@@ -1,0 +1,152 @@
+"""GPU: the split-bf16 GEMM path (csrc/gemm_split.hip: f32 operands split exactly into 3 bf16 pieces, 6 products, f32 accumulation on
+the bf16 matrix cores) behind dsc_gemm_f32 / dsc_gemm_gn_silu_f32.  Same tolerances as the exact-f32 MFMA kernels in test_gpu_ops.py
+(2e-6 of the result's max against an f64 evaluation), plus: the plane split is EXACT, and the error against f64 is not larger than
+the f32 path's on the same operands (the GO criterion of the round-3 experiment, profiles/r03_bf16x6_*.txt)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rms_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def planes_to_f32(planes):
+    return (planes.to(torch.int32) << 16).view(torch.float32)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 3e4])
+def test_plane_split_is_exact_and_transposable(scale):
+    """w1 + w2 + w3 == w bit for bit at any magnitude (bf16 keeps the f32 exponent range); the transposed form holds w^T."""
+    from diffuscene_amd import ops
+    w = (torch.randn(384, 160, generator=torch.Generator().manual_seed(1)) * scale).to(dev())
+    w[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.5e-30, 65504.0, 1.0 + 2 ** -23, -(1.0 - 2 ** -24)], device=dev())
+    p, pt = ops.split_planes([(w, None, False), (w, None, True)])
+    f = planes_to_f32(p)
+    assert torch.equal((f[0] + f[1]) + f[2], w)
+    ft = planes_to_f32(pt)
+    assert tuple(pt.shape) == (3, 160, 384) and torch.equal((ft[0] + ft[1]) + ft[2], w.t())
+    # a strided view (rows of a wider buffer) splits like its contiguous copy
+    wide = torch.randn(64, 512, device=dev())
+    (pv,) = ops.split_planes([(wide[:, 128:384], None, False)])
+    (pc,) = ops.split_planes([(wide[:, 128:384].contiguous(), None, False)])
+    assert torch.equal(pv, pc)
+
+
+@pytest.mark.parametrize("m,n,k", [(20480, 512, 512), (5376, 512, 512), (1536, 1024, 512), (300, 128, 96), (777, 384, 1024),
+                                   (20480, 3072, 512), (256, 2048, 2048)])
+def test_split_gemm_plain(m, n, k, monkeypatch):
+    from diffuscene_amd import ops
+    a, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=0.1), rnd(n, seed=3)
+    ad, wd, bd = a.to(dev()), w.to(dev()), b.to(dev())
+    (pl,) = ops.split_planes([(wd, None, False)])
+    y = ops.gemm(ad, wd, bd, w_planes=pl)
+    y32 = ops.gemm(ad, wd, bd)
+    ref = a.double() @ w.double().T + b.double()
+    assert rel(y, ref) < 2e-6, (m, n, k, rel(y, ref))
+    # same rounding-noise class as the exact-f32 kernel, whose own rms moves by 30 % with its tile's summation order (measured:
+    # 0.8 .. 1.4 x the f32 kernel's at K >= 128; 2 x at K = 96 where both are ~1e-7)
+    assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
+    assert not torch.equal(y, y32), "the split path did not take this launch (results are bit-identical to the f32 kernel)"
+
+
+@pytest.mark.parametrize("act_out", [0, 1, 2])
+def test_split_gemm_two_segments_residual_activation(act_out):
+    """torch.cat of a skip connection = second K segment (own row stride), fused GELU / SiLU, residual, ragged M."""
+    from diffuscene_amd import ops
+    m, n = 2000, 512
+    wide = rnd(m, 1536, seed=4)                      # a1 = a column slice of a wider buffer: lda1 != lda2
+    a1, a2 = wide[:, 512:1024], rnd(m, 512, seed=5)
+    w, b, r = rnd(n, 1024, seed=6, scale=0.05), rnd(n, seed=7), rnd(m, n, seed=8)
+    wd = w.to(dev())
+    (pl,) = ops.split_planes([(wd, None, False)])
+    y = ops.gemm(wide.to(dev())[:, 512:1024], wd, b.to(dev()), a2=a2.to(dev()), residual=r.to(dev()), act_out=act_out, w_planes=pl)
+    z = torch.cat([a1, a2], 1).double() @ w.double().T + b.double()
+    if act_out == 1:
+        z = F.gelu(z)
+    elif act_out == 2:
+        z = F.silu(z)
+    assert rel(y, z + r.double()) < 2e-6
+
+
+def _gn_ref(a, w, b, gamma, beta, N, ss, mode, res, idx=None):
+    B = a.shape[0] // N
+    z = a.double() @ w.double().T + b.double()
+    zg = z.view(B, N, -1, 64)
+    mu = zg.mean(dim=(1, 3), keepdim=True)
+    var = zg.var(dim=(1, 3), unbiased=False, keepdim=True)
+    y = ((zg - mu) / (var + 1e-5).sqrt()).view(B, N, -1) * gamma.double() + beta.double()
+    n = w.shape[0]
+    if mode == 1:
+        s = ss.double().view(B, N, 2 * n)
+    elif mode == 2:
+        s = ss.double()[:, None, :]
+    elif mode == 3:
+        s = ss.double()[None, :, :]
+    elif mode == 4:
+        s = ss.double()[idx][:, None, :]
+    if mode:
+        y = y * (s[..., :n] + 1) + s[..., n:]
+    y = F.silu(y).view(B * N, n)
+    return z, (y + res.double() if res is not None else y)
+
+
+@pytest.mark.parametrize("B,N,mode", [(256, 80, 2), (64, 80, 4), (37, 80, 1), (16, 72, 3), (33, 64, 2), (40, 50, 3), (128, 21, 2),
+                                      (19, 32, 1), (50, 17, 0), (24, 40, 4)])
+def test_split_gemm_groupnorm_block(B, N, mode):
+    """Block.forward in one launch on the split path: every conditioning mode, scene lengths of every RB class (17..80), the saved
+    pre-activation, residual; against f64 and next to the exact-f32 kernel."""
+    from diffuscene_amd import ops
+    M, n, k = B * N, 512, 512
+    a, w, b = rnd(M, k, seed=11), rnd(n, k, seed=12, scale=0.08), rnd(n, seed=13)
+    gamma, beta, res = rnd(n, seed=14) + 1.5, rnd(n, seed=15), rnd(M, n, seed=16)
+    rows = {0: 1, 1: M, 2: B, 3: N, 4: 1000}[mode]
+    ss = rnd(rows, 2 * n, seed=17, scale=0.3) if mode else None
+    idx = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(3)) if mode == 4 else None
+    d = dev()
+    wd = w.to(d)
+    (pl,) = ops.split_planes([(wd, None, False)])
+    kw = dict(scale_shift=ss.to(d) if mode else None, ss_mode=mode, residual=res.to(d), ss_index=idx.to(d) if mode == 4 else None)
+    pre, pre32 = torch.zeros(M, n, device=d), torch.zeros(M, n, device=d)
+    y = ops.gemm_gn_silu(a.to(d), wd, b.to(d), gamma.to(d), beta.to(d), N, preact=pre, w_planes=pl, **kw)
+    y32 = ops.gemm_gn_silu(a.to(d), wd, b.to(d), gamma.to(d), beta.to(d), N, preact=pre32, **kw)
+    z, ref = _gn_ref(a, w, b, gamma, beta, N, ss, mode, res, idx)
+    assert rel(pre, z) < 2e-6 and rel(y, ref) < 5e-6, (rel(pre, z), rel(y, ref))
+    assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
+    assert not torch.equal(pre, pre32), "the split path did not take this launch"
+
+
+def test_split_path_falls_back_where_it_does_not_apply():
+    """Shapes the split kernel does not cover (n not a multiple of 128, unaligned output slices, a handful of rows, scenes of <= 16
+    or > 80 tokens) run the exact-f32 kernel: same results as without planes, no error."""
+    from diffuscene_amd import ops
+    d = dev()
+    a, w, b = rnd(300, 512, seed=1).to(d), rnd(128, 512, seed=2, scale=0.1).to(d), rnd(128, seed=3).to(d)
+    (pl,) = ops.split_planes([(w, None, False)])
+    out = torch.zeros(300, 200, device=d)
+    y1 = ops.gemm(a, w, b, out=out[:, 3:131], w_planes=pl).clone()         # unaligned column offset
+    assert torch.equal(y1, ops.gemm(a, w, b))
+    assert torch.equal(ops.gemm(a[:100], w, b, w_planes=pl), ops.gemm(a[:100], w, b))      # < 256 rows
+    for N in (12, 96):
+        M = 8 * N
+        x = rnd(M, 512, seed=5).to(d)
+        w5, b5, g5, be5 = rnd(512, 512, seed=6, scale=0.1).to(d), rnd(512, seed=7).to(d), (rnd(512, seed=8) + 1.5).to(d), rnd(512, seed=9).to(d)
+        (p5,) = ops.split_planes([(w5, None, False)])
+        assert torch.equal(ops.gemm_gn_silu(x, w5, b5, g5, be5, N, w_planes=p5), ops.gemm_gn_silu(x, w5, b5, g5, be5, N))

@@ -19,11 +19,11 @@ SO_NOSLP = os.path.join(ROOT, "tools", "libgemm_bf16x6_noslp.so")   # scalar f32
 
 
 def build():
-    variants = ((SO, []), (SO_NOSLP, ["-fno-slp-vectorize"]), (SO.replace(".so", "_researly.so"), ["-DRES_EARLY"]),
-                (SO.replace(".so", "_reswarm.so"), ["-DRES_WARM"]), (SO.replace(".so", "_resboth.so"), ["-DRES_WARM", "-DRES_EARLY"]))
-    for so, extra in variants:
+    variants = ((SO, [], "gemm_bf16x6.hip"), (SO_NOSLP, ["-fno-slp-vectorize"], "gemm_bf16x6.hip"),
+                (SO.replace(".so", "_v5.so"), [], "gemm_bf16x6_v5.hip"))
+    for so, extra, src in variants:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra +
-                              [os.path.join(ROOT, "tools", "gemm_bf16x6.hip"), "-o", so])
+                              [os.path.join(ROOT, "tools", src), "-o", so])
         print("built", so)
 
 
@@ -44,7 +44,23 @@ def main():
     lib = C.CDLL(opt("--so", SO_NOSLP if "--noslp" in sys.argv else SO))
     print("so:", opt("--so", "default"))
     print("library:", "no-SLP build (scalar subtractions)" if "--noslp" in sys.argv else "default build (v_pk_add_f32 in the split)")
-    lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    FM = hasattr(lib, "bf16x6_layout_fragment_major")       # second generation: fragment-major weight planes
+    if FM:
+        lib.bf16x6_split_planes_nk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    else:
+        lib.bf16x6_split_planes.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+
+    def split_into(wt, planes_t, s_):
+        if FM:
+            assert lib.bf16x6_split_planes_nk(wt.data_ptr(), wt.shape[0], wt.shape[1], planes_t.data_ptr(), s_) == 0
+        else:
+            assert lib.bf16x6_split_planes(wt.data_ptr(), wt.numel(), planes_t.data_ptr(), s_) == 0
+
+    def planes_nk(planes_t, n_, k_):
+        """planes as [3][n][k] whatever the storage order"""
+        if not FM:
+            return planes_t
+        return planes_t.view(3, n_ // 16, k_ // 32, 4, 16, 8).permute(0, 1, 4, 2, 3, 5).reshape(3, n_, k_)
     lib.bf16x6_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,   # x x2 k1 lda planes bias out ldc
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,                                # m n k act residual ldr
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,                        # gn gamma beta eps ss ld_ss
@@ -53,6 +69,9 @@ def main():
 
     def ptr(t):
         return t.data_ptr() if t is not None else None
+
+    def flops_(K_):
+        return 2.0 * M * NOUT * K_
 
     def launch6(xin, planes_t, bias, out, m, n, k, products, pipe, x2=None, k1=None, act=0, residual=None, gn=None, tile=0, stream=None,
                 ntok=0, ss_mode=2, ss_index=None, preact=None):
@@ -70,7 +89,7 @@ def main():
     variants = [(6, 0), (6, 1), (6, 2), (6, 3), (3, 2), (1, 0), (1, 3)]          # (products, pipeline); pipeline 3 = split once per block at staging
     if opt("--variants", None):                 # e.g. --variants 6:1,6:3 : one process per risky variant, a GPU fault only loses that run
         variants = [tuple(int(v) for v in t.split(":")) for t in opt("--variants", "").split(",")]
-    gn_pipes = [pp for pp in (1, 2, 3) if (6, pp) in variants]
+    gn_pipes = [pp for pp in ((0, 1, 2, 3) if FM else (1, 2, 3)) if (6, pp) in variants]
     extras = "--no-extras" not in sys.argv      # sections 6 and 7 (two segments, GELU + residual, n = 384, N = 21)
     torch.manual_seed(0)
     for K in [int(x) for x in opt("--k", "512,1024").split(",")]:
@@ -81,14 +100,14 @@ def main():
         s = ops.stream_ptr()
 
         def split(wt):
-            assert lib.bf16x6_split_planes(wt.data_ptr(), wt.numel(), planes.data_ptr(), s) == 0
+            split_into(wt, planes, s)
 
         def run(v, out, xin=x, bias=b):
             launch6(xin, planes, bias, out, M, NOUT, K, v[0], v[1], stream=s)
 
         # 1. plane split is exact: w1 + w2 + w3 == w bit for bit
         split(w)
-        pf = (planes.to(torch.int32) << 16).view(torch.float32)
+        pf = (planes_nk(planes, NOUT, K).contiguous().to(torch.int32) << 16).view(torch.float32)
         exact = bool(torch.equal(pf[0] + pf[1] + pf[2], w))
         print("K=%d  plane split exact: %s" % (K, exact), flush=True)
 
@@ -121,6 +140,87 @@ def main():
             run(v, outs[v])
             torch.cuda.synchronize()
             print("K=%d  bf16 split products=%d pipe=%d   max %.2e  rms %.2e" % ((K, v[0], v[1]) + err(outs[v])), flush=True)
+
+        # 3a. attribution probes of the second generation (wrong results on purpose): which stream's latency the K loop waits for
+        if FM and "--probes" in sys.argv:
+            o_ = torch.zeros(M, NOUT, device=dev)
+            for name, act in (("product form", 0), ("token rows from K tile 0 only", 64), ("weight fragments from K tile 0 only", 256),
+                              ("both", 320)):
+                for v in [v for v in variants if v[0] == 6]:
+                    for _ in range(100):
+                        launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], act=act, stream=s)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(50):
+                        launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], act=act, stream=s)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    print("K=%d probe pipe=%d %-40s %.1f us" % (K, v[1], name, e0.elapsed_time(e1) * 20.0), flush=True)
+
+        # 3c. sustained rate: every kernel alone for ~0.3 s (the power management averages over milliseconds: a 10-launch burst
+        #     between other kernels can run above the sustained clock).  Launches go through a captured graph of 50 (no host gaps).
+        if "--sustained" in sys.argv:
+            o_ = torch.zeros(M, NOUT, device=dev)
+            gp_ = ops.make_gemm_args(x, w, o_, b)
+            cands = [("dsc_gemm_f32", lambda: ops.run_gemm(gp_))] + [
+                ("bf16 split products=%d pipe=%d" % v, (lambda v=v: launch6(x, planes, b, o_, M, NOUT, K, v[0], v[1], stream=ops.stream_ptr())))
+                for v in variants if v[0] == 6]
+            for rep in range(2):
+                for name, fn in cands:
+                    g_ = torch.cuda.CUDAGraph()
+                    fn()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g_):
+                        for _ in range(50):
+                            fn()
+                    for _ in range(40):
+                        g_.replay()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(60):
+                        g_.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1000.0 / 3000
+                    print("K=%d sustained (rep %d) %-34s %7.1f us  %6.1f TF f32-equivalent" % (K, rep, name, us, flops_(K) / us / 1e6), flush=True)
+
+        # 3b. phase stamps of one warm launch (second generation only): where the launch's time goes, per block
+        if FM and "--stamps" in sys.argv:
+            lib.bf16x6_set_stamps.argtypes = [C.c_void_p]
+            gamma_, beta_ = torch.rand(NOUT, device=dev) + 0.5, torch.randn(NOUT, device=dev) * 0.1
+            ss_, res_ = torch.randn(B, 2 * NOUT, device=dev) * 0.1, torch.randn(M, NOUT, device=dev)
+            for v in [v for v in variants if v[0] == 6]:
+                for gn_ in (False, True):
+                    nblk = (M // 160) * (NOUT // 128)
+                    st = torch.zeros(nblk, 8, device=dev, dtype=torch.int64)
+                    o_ = torch.zeros(M, NOUT, device=dev)
+
+                    def go():
+                        if gn_:
+                            launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], residual=res_, gn=(gamma_, beta_, ss_), stream=s)
+                        else:
+                            run(v, o_)
+                    for _ in range(60):
+                        go()
+                    torch.cuda.synchronize()
+                    lib.bf16x6_set_stamps(st.data_ptr())
+                    go()
+                    torch.cuda.synchronize()
+                    lib.bf16x6_set_stamps(None)
+                    w_ = st[:, :4].double() * 10.0          # ns (100 MHz wall clock)
+                    c_ = st[:, 4:].double()
+                    t0 = float(w_[:, 0].min())
+                    first, second = slice(0, nblk // 2), slice(nblk // 2, nblk)
+                    for name, sl in (("first-half blocks", first), ("second-half blocks", second)):
+                        ww, cc = w_[sl], c_[sl]
+                        print("K=%d stamps pipe=%d %s %s: start %.1f..%.1f us | prologue %.1f us (%.0f cyc) | K loop %.1f us (%.0f cyc, %.2f GHz) | "
+                              "epilogue %.1f us (%.0f cyc) | end %.1f..%.1f us" % (
+                                  K, v[1], "GN" if gn_ else "plain", name, (float(ww[:, 0].min()) - t0) / 1e3, (float(ww[:, 0].max()) - t0) / 1e3,
+                                  float((ww[:, 1] - ww[:, 0]).mean()) / 1e3, float((cc[:, 1] - cc[:, 0]).mean()),
+                                  float((ww[:, 2] - ww[:, 1]).mean()) / 1e3, float((cc[:, 2] - cc[:, 1]).mean()),
+                                  float((cc[:, 2] - cc[:, 1]).mean()) / max(float((ww[:, 2] - ww[:, 1]).mean()), 1.0),
+                                  float((ww[:, 3] - ww[:, 2]).mean()) / 1e3, float((cc[:, 3] - cc[:, 2]).mean()),
+                                  (float(ww[:, 3].min()) - t0) / 1e3, (float(ww[:, 3].max()) - t0) / 1e3), flush=True)
 
         # 4. timing, round-robin after a clock warm-up; "prod" = the product kernel on the same operands
         yp = torch.empty(M, NOUT, device=dev)
@@ -241,12 +341,12 @@ def main():
             h = K // 2
             xa, xb_ = x[:, :h].contiguous(), x[:, h:].contiguous()
             y2 = torch.zeros(M, NOUT, device=dev)
-            launch6(xa, planes, b, y2, M, NOUT, K, 6, 2 if K % 64 == 0 else 1, x2=xb_, k1=h, stream=s)
+            launch6(xa, planes, b, y2, M, NOUT, K, 6, 1 if FM else (2 if K % 64 == 0 else 1), x2=xb_, k1=h, stream=s)
             torch.cuda.synchronize()
             print("K=%d  two segments (%d+%d)           max %.2e  rms %.2e" % ((K, h, h) + err(y2)), flush=True)
         res2 = torch.randn(M, NOUT, device=dev)
         y3 = torch.zeros(M, NOUT, device=dev)
-        launch6(x, planes, b, y3, M, NOUT, K, 6, 2, act=1, residual=res2, stream=s)
+        launch6(x, planes, b, y3, M, NOUT, K, 6, 1 if FM else 2, act=1, residual=res2, stream=s)
         yp3 = ops.gemm(x, w, b, residual=res2, act_out=1)
         torch.cuda.synchronize()
         print("K=%d  GELU + residual vs dsc_gemm_f32: max |diff| / rms = %.2e" % (K, float((y3 - yp3).abs().max()) / float(yp3.pow(2).mean().sqrt())),
@@ -254,7 +354,7 @@ def main():
         n3 = 384
         w3 = torch.randn(n3, K, device=dev) / K ** 0.5
         planes3 = torch.empty(3, n3, K, device=dev, dtype=torch.int16)
-        assert lib.bf16x6_split_planes(w3.data_ptr(), w3.numel(), planes3.data_ptr(), s) == 0
+        split_into(w3, planes3, s)
         y4 = torch.zeros(M, n3, device=dev)
         ref3 = x.double() @ w3.double().t()
         for pp in (1, 2):
@@ -288,7 +388,7 @@ def main():
     w = torch.randn(NOUT, K, device=dev) / K ** 0.5
     b = torch.randn(NOUT, device=dev) * 0.1
     planes = torch.empty(3, NOUT, K, device=dev, dtype=torch.int16)
-    assert lib.bf16x6_split_planes(w.data_ptr(), w.numel(), planes.data_ptr(), s) == 0
+    split_into(w, planes, s)
     gamma, beta = torch.rand(NOUT, device=dev) + 0.5, torch.randn(NOUT, device=dev) * 0.1
     ss = torch.randn(B2, 2 * NOUT, device=dev) * 0.1
     res = torch.randn(M2, NOUT, device=dev)
@@ -305,15 +405,15 @@ def main():
     y21 = torch.zeros(M2, NOUT, device=dev)
     torch.cuda.synchronize()
     print("N=21  GN  dsc_gemm_gn_silu_f32          max %.2e" % (float((yp.double() - ref_gn).abs().max()) / rms_gn), flush=True)
-    for pp in (1, 2, 3):
+    for pp in ((0, 1) if FM else (1, 2, 3)):
         y21.zero_()
         launch6(x, planes, b, y21, M2, NOUT, K, 6, pp, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)
         torch.cuda.synchronize()
         print("N=21  GN  bf16 split x6 pipe=%d          max %.2e" % (pp, float((y21.double() - ref_gn).abs().max()) / rms_gn), flush=True)
     for name, fn in (("dsc_gemm_gn_silu_f32", lambda: ops.run_gemm(ggn, gn=True)),
                      ("bf16 split x6 pipe=1", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 1, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)),
-                     ("bf16 split x6 pipe=2", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 2, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)),
-                     ("bf16 split x6 pipe=3", lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 3, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2))):
+                     ("bf16 split x6 pipe=%d" % (0 if FM else 2), lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 0 if FM else 2, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2)),
+                     ("bf16 split x6 pipe=%d" % (1 if FM else 3), lambda: launch6(x, planes, b, y21, M2, NOUT, K, 6, 1 if FM else 3, residual=res, gn=(gamma, beta, ss), stream=s, ntok=N2))):
         for _ in range(50):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
