@@ -126,10 +126,14 @@ __global__ __launch_bounds__(T, 1) void gemm_split_kernel(const dsc_gemm_args p,
     }
     const int row0 = rb * WM * ntok, col0 = cb * BN;     // first global token row of the block
     const int rows_here = p.m - row0;                    // valid global rows from row0 on (may exceed the block)
-    const float* const xb1 = p.a1 + (int64_t)row0 * p.lda1;
-    const float* const xb2 = p.a2 ? p.a2 + (int64_t)row0 * p.lda2 : xb1;
-    const uint16_t* const wb = p.w_planes + (int64_t)col0 * K;
-    const int plane_bytes = p.n * K * 2;
+    // grouped launch (batch > 1): problem z = blockIdx.y; its weights are rows [z n, (z+1) n) of ONE stacked matrix whose planes
+    // are [3][batch n][K]
+    const int z = blockIdx.y;
+    const float* const xb1 = p.a1 + (int64_t)z * p.sa1 + (int64_t)row0 * p.lda1;
+    const float* const xb2 = p.a2 ? p.a2 + (int64_t)z * p.sa2 + (int64_t)row0 * p.lda2 : xb1;
+    const uint16_t* const wb = p.w_planes + ((int64_t)z * p.n + col0) * K;
+    const int plane_bytes = p.batch * p.n * K * 2;
+    const float* const bias = p.bias ? p.bias + (int64_t)z * p.sbias : nullptr;
 
     // weight-plane DMA: chunk c = 16 channel rows x 64 B of one plane; k-octet g lands in slot g ^ ((n >> 1) & 3)
     int dvoff[NI];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(T, 1) void gemm_split_kernel(const dsc_gemm_args p,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col0 + wn * 64 + j * 16 + 4 * g);
+        if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + col0 + wn * 64 + j * 16 + 4 * g);
 #pragma unroll
         for (int i = 0; i < RB; ++i) acc[i][j] = b4;
     }
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(T, 1) void gemm_split_kernel(const dsc_gemm_args p,
     bool valid[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) valid[i] = i * 16 + l15 < ntok && srow + i * 16 + l15 < rows_here;
-    float* const ob = p.y + (int64_t)(row0 + srow + l15) * p.ldy + cbase;
-    const float* const rbp = p.residual ? p.residual + (int64_t)(row0 + srow + l15) * p.ldr + cbase : nullptr;
+    float* const ob = p.y + (int64_t)z * p.sy + (int64_t)(row0 + srow + l15) * p.ldy + cbase;
+    const float* const rbp = p.residual ? p.residual + (int64_t)z * p.sres + (int64_t)(row0 + srow + l15) * p.ldr + cbase : nullptr;
     if constexpr (!GN) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -400,7 +404,7 @@ int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
     const int scenes = (a->m + ntok - 1) / ntok;
     const unsigned grid = (unsigned)(((scenes + WM - 1) / WM) * (a->n / BN));
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((gemm_split_kernel<GN, WM, WN, RB>), dim3(grid), dim3(T), 0, s, *a, ntok);
+    hipLaunchKernelGGL((gemm_split_kernel<GN, WM, WN, RB>), dim3(grid, (unsigned)a->batch), dim3(T), 0, s, *a, ntok);
     DSC_LAUNCH_CHECK();
     return 0;
 }
@@ -415,13 +419,16 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
         const char* e = getenv("DSC_GEMM");
         return (e && e[0] == 'f') ? 0 : 1;               // DSC_GEMM=f32: exact-f32 MFMA everywhere
     }();
-    if (!mode || !a->w_planes || a->batch != 1) return DSC_SPLIT_NOT_TAKEN;
+    if (!mode || !a->w_planes) return DSC_SPLIT_NOT_TAKEN;
     const int K = a->k1 + a->k2;
+    // grouped launches: the weights of the problems must be the row blocks of one stacked matrix (planes [3][batch n][K])
+    if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3)))
+        return DSC_SPLIT_NOT_TAKEN;
     if ((a->n % 128) || (K % 32)) return DSC_SPLIT_NOT_TAKEN;
     if (!dsc_aligned16(a->w_planes) || !dsc_aligned16(a->y) || (a->ldy & 3)) return DSC_SPLIT_NOT_TAKEN;
     if (a->bias && !dsc_aligned16(a->bias)) return DSC_SPLIT_NOT_TAKEN;
     if (a->residual && (!dsc_aligned16(a->residual) || (a->ldr & 3))) return DSC_SPLIT_NOT_TAKEN;
-    if (3LL * a->n * K * 2 >= 0x7fffffffLL) return DSC_SPLIT_NOT_TAKEN;                 // 32-bit DMA offsets into the planes
+    if (3LL * a->batch * a->n * K * 2 >= 0x7fffffffLL) return DSC_SPLIT_NOT_TAKEN;      // 32-bit DMA offsets into the planes
     const int64_t ld_max = a->lda1 > a->lda2 ? a->lda1 : a->lda2;
     if (ld_max * 4 * 320 >= 0x7fffffffLL) return DSC_SPLIT_NOT_TAKEN;                   // 32-bit byte offsets inside a token tile
     const bool wide = (a->n % 256) == 0;
@@ -442,7 +449,7 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
     long best_cost = 0;
     for (int i = 0; i < 4; ++i) {
         if (cands[i].bn == 256 && !wide) continue;
-        const long nblk = (long)((a->m + cands[i].bm - 1) / cands[i].bm) * (a->n / cands[i].bn);
+        const long nblk = (long)((a->m + cands[i].bm - 1) / cands[i].bm) * (a->n / cands[i].bn) * a->batch;
         const long c = ((nblk + 255) / 256) * (long)cands[i].bm * cands[i].bn;
         if (best < 0 || c < best_cost) { best = cands[i].id; best_cost = c; }
     }

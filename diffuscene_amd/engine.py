@@ -67,25 +67,30 @@ class Plan:
 
     # ---- step emitters -------------------------------------------------------------------------
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE):
-        g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out)
-        self.keep.append((g, a, w, out, bias, a2, residual))
+        pl = self.eng.planes_of(w) if a.shape[0] >= 256 else None
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out, w_planes=pl)
+        self.keep.append((g, a, w, out, bias, a2, residual, pl))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
 
     def gemm_batched(self, a, w, out, bias, batch, sa, sw, sy, sbias, act_out=ACT_NONE):
         """`batch` independent products in one launch: operand / output pointers advance by (sa, sw, sy, sbias) floats per
         problem (a, w, out, bias describe problem 0: views into the wider buffers)."""
-        g = ops.make_gemm_args(a, w, out, bias, None, None, ACT_NONE, act_out)
+        # `w` is the first row block of the stacked weights: the split path takes the planes of the whole stack
+        stacked = w._base if w._base is not None else w
+        pl = self.eng.planes_of(stacked) if (a.shape[0] >= 256 and stacked.shape[0] == batch * w.shape[0]) else None
+        g = ops.make_gemm_args(a, w, out, bias, None, None, ACT_NONE, act_out, w_planes=pl)
         g.batch, g.sa1, g.sw, g.sy, g.sbias = batch, sa, sw, sy, sbias
-        self.keep.append((g, a, w, out, bias))
+        self.keep.append((g, a, w, out, bias, pl))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, a2=None, ss=None, ss_mode=SS_NONE, residual=None):
+        pl = self.eng.planes_of(w) if 16 < self.N <= 80 else None
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5,
                                tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
-                               ss_index=self.t_in if ss_mode == SS_BY_INDEX else None)
-        self.keep.append((g, a, w, out, bias, a2, residual, gamma, beta, ss))
+                               ss_index=self.t_in if ss_mode == SS_BY_INDEX else None, w_planes=pl)
+        self.keep.append((g, a, w, out, bias, a2, residual, gamma, beta, ss, pl))
         self.steps.append((_lib.fn("dsc_gemm_gn_silu_f32"), (C.byref(g),)))
         return out
 
@@ -333,6 +338,11 @@ class DenoiserEngine:
         self.plans = {}
         self.sig = None
         self.ws = {}
+        # split-bf16 GEMM path (csrc/gemm_split.hip): bf16 planes of every weight a plan multiplies with, re-split by refresh()
+        # whenever the parameters change.  DSC_GEMM=f32 keeps the exact-f32 MFMA kernels everywhere (no planes are made).
+        import os
+        self.split = os.environ.get("DSC_GEMM", "split") != "f32"
+        self._planes = {}
         ws_mods, t_blocks, c_blocks = [], [], []
         for rb, kind in net.resblocks_in_order():
             ws_mods += [rb.block1.proj, rb.block2.proj]
@@ -382,6 +392,23 @@ class DenoiserEngine:
             self.dec_w2 = torch.empty((Hd * D, 2 * D), device=device)
             self.dec_b2 = torch.empty((Hd * D,), device=device)
 
+    def planes_of(self, w):
+        """bf16 planes (3, n, K) of a weight the plans multiply with (None where the split path does not apply).  The entry is
+        split on registration -- the derived weights are current whenever a plan is being built -- and again by every refresh()."""
+        if not self.split:
+            return None
+        w2 = ops.as2d(w.detach() if w.requires_grad else w)
+        if w2.dim() != 2 or w2.stride(1) != 1 or not ops.planes_wanted(w2.shape[0], w2.shape[1]):
+            return None
+        key = (w2.data_ptr(), tuple(w2.shape), w2.stride(0))
+        ent = self._planes.get(key)
+        if ent is None:
+            planes = torch.empty((3,) + tuple(w2.shape), device=self.device, dtype=torch.int16)
+            with torch.no_grad():
+                ops.split_planes([(w2, planes, False)])
+            ent = self._planes[key] = (w2, planes)
+        return ent[1]
+
     def _signature(self):
         """Order-sensitive fingerprint of (version, pointer) of every parameter + the epoch counter of raw-pointer
         optimizer updates (optim.FusedAdam also bumps p._version; the counter covers updates that could not)."""
@@ -396,6 +423,7 @@ class DenoiserEngine:
         ptrs = tuple(p.data_ptr() for p in self.net.parameters())
         if getattr(self, "_ptrs", None) != ptrs:
             self.plans.clear()          # plans hold raw parameter pointers
+            self._planes.clear()
             self._ptrs = ptrs
         with torch.no_grad():
             ops.weight_standardize([m.weight for m in self.ws_mods], self.ws_out, 1e-5)
@@ -418,6 +446,8 @@ class DenoiserEngine:
                     self.dec_b1[i * H2:(i + 1) * H2].copy_(seq[0].bias)
                     self.dec_w2[i * D:(i + 1) * D].copy_(seq[2].weight.view(D, H2))
                     self.dec_b2[i * D:(i + 1) * D].copy_(seq[2].bias)
+            if self._planes:
+                ops.split_planes([(w2, planes, False) for w2, planes in self._planes.values()])
         self.sig = sig
         self._ss_table_sig = None          # the per-timestep table is stale now (recomputed in place on demand)
 

@@ -77,7 +77,9 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
     if ss_index is not None:
         g.ss_index = _dev(ss_index, "ss_index", torch.int64).data_ptr()
     if w_planes is not None:
-        if w_planes.dtype != torch.int16 or tuple(w_planes.shape) != (3, g.n, g.k1 + g.k2) or not w_planes.is_contiguous():
+        # (3, n, K); a grouped launch (batch set by the caller afterwards) passes the planes of the stacked weights (3, batch n, K)
+        if (w_planes.dtype != torch.int16 or w_planes.dim() != 3 or w_planes.shape[0] != 3 or w_planes.shape[1] % g.n
+                or w_planes.shape[2] != g.k1 + g.k2 or not w_planes.is_contiguous()):
             raise RuntimeError("w_planes must be a contiguous int16 tensor of shape (3, %d, %d)" % (g.n, g.k1 + g.k2))
         g.w_planes = w_planes.data_ptr()
     return g

@@ -73,7 +73,8 @@ typedef struct dsc_gemm_args {
     float* preact; int64_t ld_preact;            /* optional: pre-norm conv output z = [A1|A2].W^T + bias, saved for backward */
     const int64_t* ss_index;                     /* DSC_SS_BY_INDEX: device int64 per scene (the timestep vector t) */
     /* ---- optional: W pre-split into three bf16 planes [3][n][k1+k2] by dsc_split_bf16x3_f32 (same values as w) ----
-     * When set (and batch == 1, n % 128 == 0, 16-byte aligned y / bias / residual), dsc_gemm_f32 and dsc_gemm_gn_silu_f32 compute
+     * (batch > 1: the planes [3][batch n][k] of the stacked weights, sw == n k.)
+     * When set (and n % 128 == 0, 16-byte aligned y / bias / residual), dsc_gemm_f32 and dsc_gemm_gn_silu_f32 compute
      * the SAME f32 product on the bf16 matrix cores: both operands split exactly into 3 bf16 pieces, the 6 significant piece
      * products accumulated in f32 (error vs f64 <= the exact-f32 MFMA path's, ~1.5x faster).  NULL, an unsupported shape, or
      * DSC_GEMM=f32 in the environment: the exact-f32 MFMA kernel runs. */
