@@ -58,6 +58,41 @@ class HipBackend:
         self.scratch_floats = 0
         self.scratch = None
         self._scratch_users = []
+        # split-bf16 GEMM path (csrc/gemm_split.hip): bf16 planes of every weight operand of a large product; the plan inserts the
+        # launches that refresh them (once per step and phase) -- DSC_GEMM=f32 keeps the exact-f32 MFMA kernels
+        import os
+        self.split = os.environ.get("DSC_GEMM", "split") != "f32"
+        self._planes = {}
+        self._planes_new = []
+
+    def planes_of(self, w, rows):
+        """bf16 planes of weight operand ``w`` ([n][K], rows contiguous) for a product with ``rows`` activation rows, or None."""
+        from . import ops
+        if not self.split or rows < 256 or w.dim() != 2 or w.stride(1) != 1 or not ops.planes_wanted(w.shape[0], w.shape[1]):
+            return None
+        key = (w.data_ptr(), tuple(w.shape), w.stride(0))
+        ent = self._planes.get(key)
+        if ent is None:
+            planes = torch.empty((3,) + tuple(w.shape), device=self.device, dtype=torch.int16)
+            ent = self._planes[key] = (w, planes)
+            self._planes_new.append(ent)
+        return ent[1]
+
+    def split_steps(self):
+        """Launches that (re-)split every weight registered since the last call; the plan places them where those weights are
+        final for the step (after the weight standardisation in the forward list, after the transposes in the backward list)."""
+        from . import ops
+        ents, self._planes_new = self._planes_new, []
+        steps = []
+        for i in range(0, len(ents), self.lib.WS_MAX):
+            part = ents[i:i + self.lib.WS_MAX]
+            arr = (self.lib.SplitItem * len(part))()
+            for j, (w, planes) in enumerate(part):
+                ptr, ldw = ops._mat(w, "w")
+                arr[j].w, arr[j].ldw, arr[j].rows, arr[j].cols, arr[j].planes, arr[j].transpose = (
+                    ptr, ldw, w.shape[0], w.shape[1], planes.data_ptr(), 0)
+            steps.append(self._call("dsc_split_bf16x3_f32", arr, len(part), keep=(arr, part)))
+        return steps
 
     # -- helpers
     def _mat(self, t):
@@ -87,7 +122,6 @@ class HipBackend:
     # -- forward ops
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE):
         from . import ops
-        g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
         m, K = a.shape
         # short, deep products (time / context MLPs: m = B or N rows, K >= 1024): split K over the batch dimension
         tiles = ((m + 63) // 64) * ((out.shape[1] + 63) // 64)        # output tiles: fewer than CUs -> parallelise K instead
@@ -95,16 +129,20 @@ class HipBackend:
             splits = next((s for s in (8, 4, 2) if K % (32 * s) == 0 and K // s >= 128), 0)
             if splits:
                 fn = self.lib.fn("dsc_gemm_splitk_f32")
-                self.keep.append((g, a, w, out, bias, residual))
                 floats = splits * m * out.shape[1]
+                g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
+                self.keep.append((g, a, w, out, bias, residual))
                 return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
-        return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual))
+        pl = self.planes_of(w, m)
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out, w_planes=pl)
+        return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl))
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):
         from . import ops
+        pl = self.planes_of(w, a.shape[0]) if 16 < n_tok <= 80 else None
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5, tokens_per_scene=n_tok,
-                               scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE, preact=preact)
-        return self._call("dsc_gemm_gn_silu_f32", C.byref(g), keep=(g, a, w, out, bias, gamma, beta, a2, ss, residual, preact))
+                               scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE, preact=preact, w_planes=pl)
+        return self._call("dsc_gemm_gn_silu_f32", C.byref(g), keep=(g, a, w, out, bias, gamma, beta, a2, ss, residual, preact, pl))
 
     def smallk(self, x, w, bias, out, act_out=ACT_NONE):
         xp, ldx = self._mat(x)
@@ -813,6 +851,7 @@ class TrainPlan:
         self.ws_t = {id(m): self.new(_as2d(m.weight).shape[1], _as2d(m.weight).shape[0]) for m in ws_mods}
         self._ws_pending = []
         self.emit(be.ws([_as2d(m.weight) for m in ws_mods], [self.ws_std[id(m)] for m in ws_mods]))
+        self._fwd_split_at = len(self.fwd)            # the forward list's weight-plane splits go here (standardised weights final)
         for m in ws_mods:
             self._transposes.append((self.ws_std[id(m)], self.ws_t[id(m)]))
         # ---- conditioning
@@ -984,6 +1023,9 @@ class TrainPlan:
             bounds = (list(diff._centroids[0]) + list(diff._centroids[1]) + list(diff._sizes[0]) + list(diff._sizes[1])) \
                 if iou else None
         mean_type = {"eps": ops.MEAN_EPS, "x0": ops.MEAN_X0, "v": ops.MEAN_V}[diff.model_mean_type]
+        if hasattr(be, "split_steps"):                # bf16 planes of the forward's weight operands, refreshed once per step
+            sp = be.split_steps()
+            self.fwd[self._fwd_split_at:self._fwd_split_at] = sp
         self.n_fwd_only = len(self.fwd)
         self.emit(be.loss(self.target, self.out.view(B, N, -1), self.x_t, self.t, tb, ca, cb_, bounds, dims,
                           bool(diff.loss_separate), iou, mean_type, self.losses, self.parts, self.dout.view(B, N, -1),
@@ -1007,6 +1049,8 @@ class TrainPlan:
         self.bwd = []
         self._cur = self.bwd
         self.emit(be.transpose_many(self._transposes))
+        if hasattr(be, "split_steps"):                # planes of the transposed weights (operands of the input-gradient GEMMs)
+            self.emit(be.split_steps())
         shift = len(self.bwd)
         self.bwd.extend(body)
         self.bwd_writes = [(i + shift, r) for i, r in self.bwd_writes]
