@@ -65,7 +65,8 @@ class TnGroup(C.Structure):
                 ("dbias", C.c_void_p),
                 ("m", C.c_int32), ("n", C.c_int32), ("kvalid", C.c_int32),
                 ("tile0", C.c_int32),
-                ("ws_offset", C.c_int64)]
+                ("ws_offset", C.c_int64),
+                ("tile0s", C.c_int32)]
 
 
 class ColsumItem(C.Structure):
@@ -129,6 +130,8 @@ SIGNATURES = {
     "dsc_gemm_tn_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dsc_gemm_tn_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_int64,
                                           C.c_void_p]),
+    "dsc_gemm_tn_grouped_split_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64,
+                                                C.c_int64, C.c_void_p]),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,

@@ -1,0 +1,245 @@
+#pragma once
+// Weight-gradient GEMM on the bf16 matrix cores with f32 accuracy (the "split-bf16" arithmetic of gemm_split.hip: both operands split
+// exactly into three bf16 pieces, six products, f32 accumulation), grouped over many layers like gemm_tn_grouped_kernel.
+//
+//   dw[n][k] = sum_m dy[m][n] * [a1 | a2][m][k]              dy, a1, a2: f32 activations in HBM; dw: f32 (slice of the flat gradient G)
+//
+// The reduction runs over TOKENS, the slow dimension of both operands: an MFMA fragment needs 8 consecutive tokens of one channel.
+// So the split happens once per block at staging: a thread loads 8 consecutive tokens of ONE channel (8 dword loads, coalesced
+// across the lanes' consecutive channels), splits them and writes three 16-byte bf16x8 pieces into channel-major LDS planes
+// [3][384 channels][32 tokens].  Fragments are then one 16-byte read per plane for both operands.
+//
+// Block: 256 dy-channels (n) x 128 x-channels (k) of the output, one slice of the token range (blockIdx.y; slices > 1 write slabs
+// that reduce_grouped_kernel sums in a fixed order), 8 waves as 4 (n) x 2 (k), wave tile 64 x 64 = 4 x 4 MFMA blocks of 16 x 16,
+// 32 tokens per step, two LDS stages of 72 KiB.  The MFMA computes dw^T blocks (x as the row operand) so that a lane holds 4
+// consecutive k of one n: 16-byte stores.  Channels past n / K and tokens past m need no masking code: buffer loads past the end of
+// an operand return zeros, and whatever a channel past the edge reads only reaches output rows / columns that are never stored.
+// The bias gradient (column sums of dy) rides in the staging registers of the k-tile-0 blocks.
+#include "dsc_common.h"
+
+namespace dsc_tn_split {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BN = 256, BKO = 128, COLS = BN + BKO, BMS = 32, NW = 8, T = NW * 64;
+constexpr int PLANE = COLS * BMS * 2;                 // 24576 B: one bf16 plane, channel-major (64 B per channel)
+constexpr int STAGE = 3 * PLANE;                      // 73728 B
+constexpr int NIT = COLS * 4 / T;                     // 3 (channel, token-octet) items per thread and step
+constexpr int SMEM = 2 * STAGE + 4 * BN * 4;          // + [4 token octets][256 channels] f32 for the bias gradient
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    u32x4 a, b, c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = x[2 * q], x1 = x[2 * q + 1];
+        const unsigned u1 = cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - bf_lo(u1), r1 = x1 - bf_hi(u1);
+        const unsigned u2 = cvt_pk_bf16(r0, r1);
+        a[q] = u1;
+        b[q] = u2;
+        c[q] = cvt_pk_bf16(r0 - bf_lo(u2), r1 - bf_hi(u2));
+    }
+    p1 = __builtin_bit_cast(bf16x8, a);
+    p2 = __builtin_bit_cast(bf16x8, b);
+    p3 = __builtin_bit_cast(bf16x8, c);
+}
+
+struct Prob {
+    const float* a1; long lda1; int k1;
+    const float* a2; long lda2; int k2;
+    const float* dy; long ldd;
+    float* out; long ldo; float* bias_out;
+    int m, n, kvalid;
+    long chunk, slab, bias_slab;
+};
+
+// it: 128-wide k tile, jt: 256-wide n tile, split: token slice
+__device__ __forceinline__ void tn_split_block(const Prob& p, const int it, const int jt, const int split, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wn = wave_u & 3, wk = wave_u >> 2;
+    const int n0 = jt * BN, k0 = it * BKO;
+    const long m_begin = (long)split * p.chunk;
+    const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
+    const int steps = m_end > m_begin ? (int)((m_end - m_begin + BMS - 1) / BMS) : 0;
+    const int g = lane >> 4, l15 = lane & 15;
+
+    // the x operand of this k tile: one of the two K segments (a K tile never straddles them: k1 % 128 == 0 when k2 > 0)
+    const bool seg1 = k0 < p.k1;
+    const float* const xbase = seg1 ? p.a1 + k0 : p.a2 + (k0 - p.k1);
+    const long ldx = seg1 ? p.lda1 : p.lda2;
+    const int xcols = seg1 ? p.k1 - k0 : p.k1 + p.k2 - k0;          // valid columns from xbase on
+    const float* const dbase = p.dy + n0;
+    const int dcols = p.n - n0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // num_records = bytes up to the end of the last valid row: token rows >= m read zeros (only the last slice has a ragged tail:
+    // chunk is a multiple of 32)
+    long xrec = ((long)(p.m - 1) * ldx + xcols) * 4, drec = ((long)(p.m - 1) * p.ldd + dcols) * 4;
+    if (xrec > 0x7fffffffL) xrec = 0x7fffffffL;
+    if (drec > 0x7fffffffL) drec = 0x7fffffffL;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, (int)xrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000);
+#endif
+
+    // staging items: t = u*512 + tid -> channel c = t % 384 (0..255: dy channel n0+c, 256..383: x channel k0+c-256), token octet t / 384
+    int ivoff[NIT], ildso[NIT], bslot[NIT];
+    bool isdy[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int t = u * T + tid, c = t % COLS, og = t / COLS;
+        isdy[u] = __builtin_amdgcn_readfirstlane((u * T + wave_u * 64) % COLS) < BN;       // wave-uniform: 384 = 6 x 64
+        // channels past the edge of the operand read channel 0 (valid memory; their products are never stored)
+        const int cc = isdy[u] ? (c < dcols ? c : 0) : (c - BN < xcols ? c - BN : 0);
+        ivoff[u] = (int)((cc + 8L * og * (isdy[u] ? p.ldd : ldx)) * 4);
+        ildso[u] = c * 64 + ((og ^ ((c >> 1) & 3)) << 4);
+        bslot[u] = og * BN + c;
+    }
+    const bool do_bias = p.bias_out != nullptr && it == 0;
+    float bsum[NIT] = {0.f, 0.f, 0.f};
+    float ld[NIT][8];
+    auto load_items = [&](int step) {
+        const long mb = m_begin + (long)step * BMS;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                ld[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isdy[u] ? rdy : rx, ivoff[u],
+                                                                                           (int)((mb + e) * (isdy[u] ? p.ldd : ldx) * 4), 0));
+#else
+        (void)mb;
+#endif
+    };
+    auto store_item = [&](int u, char* stage) {
+        if (do_bias && isdy[u]) bsum[u] += ((ld[u][0] + ld[u][1]) + (ld[u][2] + ld[u][3])) + ((ld[u][4] + ld[u][5]) + (ld[u][6] + ld[u][7]));
+        bf16x8 a, b, c;
+        split8(ld[u], a, b, c);
+        *reinterpret_cast<bf16x8*>(stage + ildso[u]) = a;
+        *reinterpret_cast<bf16x8*>(stage + PLANE + ildso[u]) = b;
+        *reinterpret_cast<bf16x8*>(stage + 2 * PLANE + ildso[u]) = c;
+    };
+
+    // fragment offsets: x (row operand): channel 256 + wk*64 + kb*16 + l15; dy (column operand): channel wn*64 + nb*16 + l15
+    int xoff[4], doff[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int cx = BN + wk * 64 + b * 16 + l15, cd = wn * 64 + b * 16 + l15;
+        xoff[b] = cx * 64 + ((g ^ ((cx >> 1) & 3)) << 4);
+        doff[b] = cd * 64 + ((g ^ ((cd >> 1) & 3)) << 4);
+    }
+    f32x4 acc[4][4];                                  // [kb][nb]: lane = (n = l15 of block nb, k = 4g..4g+3 of block kb)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NMMA = 24;                          // MFMAs per dy block (4 x blocks x 6 products)
+    if (steps > 0) {
+        load_items(0);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) store_item(u, smem);
+    }
+    for (int s = 0; s < steps; ++s) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): my plane writes of step s are done
+        __syncthreads();                              // everyone's are; nobody reads the other stage any more
+        char* cur = smem + (s & 1) * STAGE;
+        char* nxt = smem + ((s + 1) & 1) * STAGE;
+        const bool more = s + 1 < steps;              // the last step re-loads its own rows (no branch around the loads) but
+        load_items(more ? s + 1 : s);                 // does not count them into the bias gradient again (below)
+        bf16x8 xf[4][3], df[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb + 1 < 4) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
+            }
+            if (nb == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the staged rows of the next step have arrived
+                __builtin_amdgcn_sched_barrier(0);
+                if (!more) {                          // wave-uniform: the duplicate of the last step must not enter the bias sums
+#pragma unroll
+                    for (int u = 0; u < NIT; ++u)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ld[u][e] = 0.f;
+                }
+            }
+            if (nb >= 1) store_item(nb - 1, nxt);
+            const bf16x8 (&d)[3] = df[nb & 1];
+            // product-major over the 4 x blocks: an accumulator comes round every 4th MFMA; small terms first
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][2], d[0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[2], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[0], acc[kb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (nb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if (nb >= 1) {
+#pragma unroll
+                for (int q = 0; q < NMMA - 2; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2), 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+
+    float* out = p.out + (long)split * p.slab;
+    if (do_bias) {
+        // every dy channel has four items (token octets) in four different threads: partial sums through LDS, fixed order
+        float* bs = reinterpret_cast<float*>(smem + 2 * STAGE);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+            if (isdy[u]) bs[bslot[u]] = bsum[u];
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.n)
+            p.bias_out[(long)split * p.bias_slab + n0 + tid] = (bs[tid] + bs[BN + tid]) + (bs[2 * BN + tid] + bs[3 * BN + tid]);
+    }
+    const bool vec = (p.ldo & 3) == 0 && (p.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int j = n0 + wn * 64 + nb * 16 + l15;               // output row (n)
+        if (j >= p.n) continue;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int i = k0 + wk * 64 + kb * 16 + 4 * g;         // output column (k), 4 consecutive
+            if (vec && i + 3 < p.kvalid) {
+                *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = acc[kb][nb];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[kb][nb][e];
+            }
+        }
+    }
+}
+
+}  // namespace dsc_tn_split

@@ -229,6 +229,8 @@ class HipBackend:
         items = sorted(items, key=lambda it: -it["dy"].shape[0])
         arr = (self.lib.TnGroup * len(items))()
         tile0, ws_off = 0, 0
+        tile0s, long_tiles_s = 0, 0                   # 256 x 128 tile numbering of the split-bf16 form
+        use_split = self.split
         per_group = []
         long_tiles, m_max = 0, max(it["dy"].shape[0] for it in items)
         for i, it in enumerate(items):
@@ -257,10 +259,32 @@ class HipBackend:
             g.m, g.n, g.kvalid, g.tile0 = m, n, kv, tile0
             nt = ((n + 127) // 128) * ((k1 + k2 + 127) // 128)
             tile0 += nt
+            g.tile0s = tile0s
+            nts = ((n + 255) // 256) * ((k1 + k2 + 127) // 128)
+            tile0s += nts
             if 2 * m >= m_max:
                 long_tiles += nt
+                long_tiles_s += nts
+            if m * max(lda, ldd, lda2) * 4 >= 0x7fffffff:
+                use_split = False                      # 32-bit byte offsets inside an operand
             per_group.append((n, kv, ldo))
         total = tile0
+        if use_split:
+            # one 8-wave block per CU: cut the tokens until the long tiles make ~8 rounds of 256 blocks
+            splits = max(1, min(32, -(-8 * 256 // max(long_tiles_s, 1))))
+            ws_off = 0
+            if splits > 1:
+                for i, (n, kv, ldo) in enumerate(per_group):
+                    if ldo != kv:
+                        raise RuntimeError("gemm_tn_grouped: split outputs must be dense [n][kvalid]")
+                    arr[i].ws_offset = ws_off
+                    ws_off += (n * kv + n) * splits
+            table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+            self.keep.append((table, items))
+            fn = self.lib.fn("dsc_gemm_tn_grouped_split_f32")
+            tp, cnt, total_s = table.data_ptr(), len(items), tile0s
+            return self._with_scratch(ws_off, lambda wp, wn: (fn, (tp, cnt, total, total_s, splits, wp if splits > 1 else None,
+                                                                    wn if splits > 1 else 0, ws_off), "dsc_gemm_tn_grouped_split_f32"))
         # the long tiles set the duration: cut the tokens until they make ~8 rounds of 2 blocks per CU (tail < 1/8); with all
         # layers of a step in one group that is 2 slabs per gradient instead of the 32 of a per-layer launch
         splits = max(1, min(32, -(-8 * 512 // max(long_tiles, 1))))

@@ -220,9 +220,17 @@ typedef struct dsc_tn_group {
     int32_t m, n, kvalid;
     int32_t tile0;
     int64_t ws_offset;
+    int32_t tile0s;   /* first tile of the group in the 256 (n) x 128 (k) numbering of dsc_gemm_tn_grouped_split_f32 */
 } dsc_tn_group;
 int dsc_gemm_tn_grouped_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, int32_t splits,
                             float* workspace, int64_t workspace_floats, int64_t workspace_needed, dsc_stream_t stream);
+/* The same launch on the bf16 matrix cores with f32 accuracy (both operands split exactly into three bf16 pieces, six products, f32
+ * accumulation; csrc/gemm_tn_split.h).  Output tiles are 256 x 128: total_tiles_split = sum over groups of
+ * ceil(n / 256) * ceil((k1 + k2) / 128), tile0s = the group's first tile in that numbering; total_tiles / tile0 stay the 128 x 128
+ * numbering (used by the slab reduction when splits > 1).  Every operand must satisfy m * ld * 4 < 2^31. */
+int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, int32_t total_tiles_split,
+                                  int32_t splits, float* workspace, int64_t workspace_floats, int64_t workspace_needed,
+                                  dsc_stream_t stream);
 
 /* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */
 int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,

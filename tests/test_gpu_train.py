@@ -396,13 +396,17 @@ def test_fused_adam_matches_torch_adam_with_clipping():
         cpu.step()
 
 
+@pytest.mark.parametrize("arith", ["split", "f32"])
 @pytest.mark.parametrize("scale", [1, 40])
-def test_grouped_weight_gradient_gemm(scale):
-    """dsc_gemm_tn_grouped_f32: many weight gradients in one launch (mixed shapes: two K segments, zero-padded small K with
-    kvalid, bias column sums, tiny token counts) vs fp64; `scale` makes the group large enough for the unsplit path."""
+def test_grouped_weight_gradient_gemm(scale, arith, monkeypatch):
+    """dsc_gemm_tn_grouped_[split_]f32: many weight gradients in one launch (mixed shapes: two K segments, zero-padded small K with
+    kvalid, bias column sums, tiny token counts, a ragged token tail) vs fp64; `scale` makes the group large enough for the unsplit
+    path; both arithmetics: the split-bf16 form (default) and the exact-f32 MFMA kernel (DSC_GEMM=f32)."""
     from diffuscene_amd.train_plan import HipBackend
+    monkeypatch.setenv("DSC_GEMM", arith)
     be = HipBackend(dev())
-    M = 1280
+    assert be.split == (arith == "split")
+    M = 1290
     shapes = [(M, 512, 512, 0, None, True), (M, 512, 512, 512, None, False), (M, 512, 32, 0, 25, True),
               (64, 1024, 512, 0, None, True), (M, 384, 512, 0, None, False), (M, 32, 512, 0, None, True)] * scale
     items, refs = [], []
@@ -417,6 +421,7 @@ def test_grouped_weight_gradient_gemm(scale):
         refs.append(((dy.double().T @ A.double())[:, :kv or K], dy.double().sum(0)))
     step = be.gemm_tn_grouped(items)
     be.finalize()
+    assert step["step"][2] == ("dsc_gemm_tn_grouped_split_f32" if arith == "split" else "dsc_gemm_tn_grouped_f32")
     be.run([step], torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     for it, (rw, rb) in zip(items, refs):
