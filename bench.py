@@ -38,6 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+SPLIT_PRODUCTS = 6                 # split-bf16 arithmetic: 6 bf16 MFMA products per f32 product (csrc/gemm_split.hip)
+DTYPE_SPLIT = "f32 (operands split 3xbf16, 6 products, f32 accumulate)"
 _T0 = time.perf_counter()
 
 
@@ -218,48 +221,86 @@ def git_head():
         return None
 
 
+def csrc_sha():
+    """Fingerprint of the kernel sources (what a PMC traffic file must have been measured on to be quoted)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "diffuscene_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def roofline_dominant_kernel(plan, N, config_name):
-    """Time the dominant kernel -- the fused WS-conv + GroupNorm + SiLU GEMM (gemm_kernel<...,GN=true>, K=512) --
-    with HIP events on the launch stream, using the very argument structs of the timed plan."""
+    """Time the dominant kernel -- the fused WS-conv + GroupNorm + SiLU GEMM (Block.forward in one launch) -- with HIP events on the
+    launch stream, using the very argument structs of the timed plan.  `frac` is quoted on the K=512 launches (47 of the 56 per
+    forward), `frac_mix` over all GN launches of a step.  With the split-bf16 arithmetic the kernel EXECUTES 6 bf16 MFMA products per
+    f32 product: achieved / peak are executed TFLOP/s against the dense bf16 peak; the algorithmic (f32-equivalent) rate stands
+    beside it."""
     import torch
     from diffuscene_amd import _lib, ops
     fn = _lib.fn("dsc_gemm_gn_silu_f32")
     steps = [a for f, a in plan.tiled_steps if f is fn]
     structs = [a[0]._obj for a in steps]          # ctypes.byref(struct) keeps the struct in ._obj
-    sel = [(a, s) for a, s in zip(steps, structs) if s.k1 + s.k2 == 512]
     s = ops.stream_ptr()
-    for _ in range(3):                     # the clocks take milliseconds to ramp after an idle sync: warm up, then time
-        for a, _ in sel:
-            fn(*a, s)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
-    ev0.record()
-    for _ in range(reps):
-        for a, _ in sel:
-            fn(*a, s)
-    ev1.record()
-    torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / (reps * len(sel))
+
+    def timed_launches(sel):
+        for _ in range(3):                 # the clocks take milliseconds to ramp after an idle sync: warm up, then time
+            for a in sel:
+                fn(*a, s)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        ev0.record()
+        for _ in range(reps):
+            for a in sel:
+                fn(*a, s)
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / (reps * len(sel))
+
+    sel512 = [a for a, st in zip(steps, structs) if st.k1 + st.k2 == 512]
+    ms = timed_launches(sel512)
+    ms_mix = timed_launches(steps)
     M = plan.B * N
     flops = 2.0 * M * 512 * 512
-    achieved = flops / (ms * 1e-3) / 1e12
+    flops_mix = sum(2.0 * M * st.n * (st.k1 + st.k2) for st in structs) / len(structs)
+    split = bool(structs[0].w_planes) and os.environ.get("DSC_GEMM", "split") != "f32" and 16 < N <= 80
+    mult, peak = (SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS) if split else (1, PEAK_FP32_MFMA_TFLOPS)
+    alg = flops / (ms * 1e-3) / 1e12
+    alg_mix = flops_mix / (ms_mix * 1e-3) / 1e12
+    kname = ("dsc_split::gemm_split_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; 3xbf16 split, 6 MFMA products)" % M
+             if split else "dsc_gemm::gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; f32 MFMA)" % M)
+    # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, separate passes:
+    # tools/gpu_round.sh pmc + tools/pmc_summary.py on the same workload -- bench.py cannot run the profiler on itself).  The file
+    # is only quoted when it was measured on THESE kernel sources (csrc fingerprint) and for the arithmetic that is running.
     traffic, traffic_src = None, None
-    # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), measured by
-    # tools/gpu_round.sh (pmc step) + tools/pmc_summary.py on the same workload -- bench.py cannot run the profiler on itself; the file records the git
-    # head it was measured at
-    for tfile in ("profiles/r02_gemm_gn_hbm_traffic.json", "profiles/r01_gemm_gn_hbm_traffic.json"):
-        path = os.path.join(ROOT, tfile)
-        if os.path.exists(path) and M == 20480:
-            with open(path) as f:
-                rec = json.load(f)
-            traffic = round(rec["hbm_bytes_per_launch"])
-            traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; measured at git %s)" % (tfile, rec.get("git_head", "?"))
-            break
-    return {"bound": "mfma", "kernel": "gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512)" % M,
-            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
-            "launches_per_step": len(steps), "algorithmic_flops_per_launch": flops,
-            "traffic": traffic, "traffic_source": traffic_src}
+    here = csrc_sha()
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_gn_hbm_traffic*.json")), reverse=True):
+        with open(path) as f:
+            rec = json.load(f)
+        if M != 20480 or rec.get("csrc_sha") != here or ("gemm_split" in (rec.get("kernel") or "")) != split:
+            continue
+        traffic = round(rec["hbm_bytes_per_launch"])
+        traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; csrc %s, git %s; per-launch average over the K=512 " \
+                      "and K=1024 launches of a forward)" % (os.path.relpath(path, ROOT), here, rec.get("git_head", "?"))
+        break
+    if traffic is None:
+        traffic_src = "no PMC file measured on these kernel sources (csrc %s): run tools/gpu_round.sh <tag> pmc" % here
+    out = {"bound": "mfma", "kernel": kname,
+           "achieved": round(alg * mult, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg * mult / peak, 4),
+           "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": len(steps), "algorithmic_flops_per_launch": flops,
+           "algorithmic_tflops": round(alg, 2),
+           "frac_mix": round(alg_mix * mult / peak, 4), "avg_launch_us_mix": round(ms_mix * 1e3, 2),
+           "mix": "%d launches with K=512, %d with K=1024" % (len(sel512), len(steps) - len(sel512)),
+           "traffic": traffic, "traffic_source": traffic_src}
+    if split:
+        out["executed_flops_per_launch"] = flops * mult
+        out["note"] = ("achieved = executed bf16-MFMA flops (6 x algorithmic) / time against the dense bf16 peak; algorithmic_tflops is the "
+                       "f32-equivalent rate (the exact-f32 MFMA kernel, DSC_GEMM=f32, peaks at %.1f)" % PEAK_FP32_MFMA_TFLOPS)
+    return out
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -371,6 +412,8 @@ def cpu_baseline(spec, mode):
     per = sum(v[0] for v in times.values()) / len(times)            # 'both': mean of the two step kinds (1:1 mix)
     model, phys = _cpu_info()
     out = {"value": round(1.0 / per, 4), "unit": "steps/s", "cores": threads, "kind": "port",
+           "pinned_by": "tests/test_oracle.py (the port vs the real reference modules, <= 2e-5; schedule tables bit-exact) and "
+                        "tests/golden/*.npz (outputs of the real reference, regenerated by oracle/make_golden*.py)",
            "sample": "full-batch oracle steps (B=%d, N=%d): %s; train = q_sample + fwd + p_losses(IoU) + bwd + "
                      "clip_grad_norm_(10) + Adam.step()" % (B, N, ", ".join("%d x %s %.2f s" % (v[1], k, v[0])
                                                                            for k, v in times.items())),
@@ -398,6 +441,67 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def ddp_selftest(args, device):
+    """--ddp-selftest: the N > 1 training step on ONE GPU.  torch.distributed 'nccl' (= RCCL) with world_size 1 and
+    DSC_DDP_FORCE=1 runs exactly what every rank of an 8-GPU job runs -- the bucket schedule of the plan, the hipGraph segments cut
+    at the bucket launches, 8 in-place all-reduces of the flat gradient buffer issued between the segment replays (each a
+    world-1 RCCL call), clip + Adam on the reduced gradients -- so its step time next to the single-GPU graph step is the
+    overhead of the data-parallel form itself (no link traffic).  Both flush schedules (DSC_DDP_FLUSH=block|end) are timed."""
+    import torch
+    import torch.distributed as dist
+    base = dict(CONFIGS[args.config])
+    if args.batch:
+        base["batch"] = args.batch
+    n, warm = max(args.steps // 2, 4), max(args.warmup, 3)
+    res = {"config": args.config, "steps": n, "warmup": warm, "rows": []}
+
+    def step_ms(spec, model):
+        tr = TrainRunner(spec, model, device, 0)
+        tr.run(warm)
+        return timed(1, lambda: tr.run(n)) / n * 1e3, tr
+
+    for B in (base["batch"], max(base["batch"] // 8, 1)):
+        spec = dict(base, batch=B)
+        os.environ.pop("DSC_DDP_FORCE", None)
+        model, _ = build_model(spec, device)
+        single, _ = step_ms(spec, model)
+        row = {"batch_per_gpu": B, "single_gpu_graph_ms": round(single, 3)}
+        log("B=%d single-GPU graph step %.3f ms" % (B, single))
+        del model
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=device)
+        os.environ["DSC_DDP_FORCE"] = "1"
+        for flush in ("block", "end"):
+            os.environ["DSC_DDP_FLUSH"] = flush
+            model, _ = build_model(spec, device)
+            ms, tr = step_ms(spec, model)
+            ent = next(iter(model._dsc_plan_runner.plans.values()))
+            red, sg = ent["reducer"], ent["graph"]
+            row["ddp_%s" % flush] = {"ms": round(ms, 3), "vs_single": round(ms / single, 4), "buckets": len(red.buckets),
+                                     "graph_segments": len(sg.segments) if sg is not None else 0,
+                                     "buckets_launched_before_the_last_segment": red.launched_during_backward // max(n + warm - 1, 1)}
+            log("B=%d DDP-mode step (%s flush) %.3f ms = %.3f x single" % (B, flush, ms, ms / single))
+            if flush == "block" and B == base["batch"]:
+                from diffuscene_amd import ddp
+                fs = model._dsc_flat
+                g = torch.zeros_like(fs.G)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    for w in [dist.all_reduce(g[s_:e_], op=dist.ReduceOp.SUM, async_op=True) for s_, e_ in fs.buckets(ddp.N_BUCKETS)]:
+                        w.wait()
+                e1.record()
+                torch.cuda.synchronize()
+                res["allreduce_world1"] = {"ms_per_step": round(e0.elapsed_time(e1) / 5, 3), "bytes": fs.numel * 4,
+                                           "what": "the 8 bucket all-reduces of one step alone, world_size 1 (launch + local copy cost, no links)"}
+            del model, tr
+        res["rows"].append(row)
+    os.environ.pop("DSC_DDP_FORCE", None)
+    dist.destroy_process_group()
+    print(json.dumps({"ddp_selftest": res, "git_head": git_head(),
+                      "dtype": "f32 (exact f32 MFMA)" if os.environ.get("DSC_GEMM", "split") == "f32" else DTYPE_SPLIT}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,6 +516,10 @@ def main():
                          "the ranks (SURVEY.md 8e: B=256 global = 32 scenes per GPU at 8 GPUs, communication-dominated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-loop", action="store_true")
+    ap.add_argument("--ddp-selftest", action="store_true",
+                    help="one GPU: time the DATA-PARALLEL form of the training step (world-1 RCCL group, reducer forced on: bucket "
+                         "schedule, hipGraph segments, 8 in-place all-reduces) next to the single-GPU graph step, at the config's "
+                         "batch and at 1/8 of it (the strong-scaling shard)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -436,6 +544,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
     rank = dist.get_rank() if ws > 1 else 0
+    if args.ddp_selftest:
+        if ws != 1:
+            raise SystemExit("bench.py: --ddp-selftest is a single-GPU run")
+        return ddp_selftest(args, device)
 
     spec = dict(CONFIGS[args.config])
     if args.batch:
@@ -503,7 +615,8 @@ def main():
             "metric": "denoiser steps/sec (%s) at B=%d, N=%d objects" % (what, B, N),
             "value": round(steps_per_s, 3), "unit": "steps/s", "n_gpus": ws, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32 (exact f32 MFMA)" if os.environ.get("DSC_GEMM", "split") == "f32" else DTYPE_SPLIT, "data": "synthetic",
             "config": {"workload": "%s (%s), B=%d scenes per GPU, N=%d, C=%d, T=1000, mode=%s"
                                    % (spec["title"], spec["yaml"], B, N, 8 + spec["class_dim"] + 32, args.mode),
                        "name": args.config, "global_batch": B * ws,
@@ -515,7 +628,13 @@ def main():
         for k, v in parts.items():
             out[k] = {"steps_per_s": round(ws / v, 3), "ms_per_step": round(v * 1e3, 3),
                       "tflops_per_gpu": round((1.0 if k == "sample" else 3.0) * F / v / 1e12, 2)}
-        out["model_frac_of_fp32_mfma_peak"] = round(out["model_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        # whole-model roofline fraction: algorithmic flops against the f32-MFMA peak for the exact-f32 arithmetic; with the split-bf16
+        # arithmetic the GEMMs (97 % of the flops) execute 6 bf16 products per f32 product: executed flops against the bf16 peak
+        if os.environ.get("DSC_GEMM", "split") == "f32":
+            out["model_frac_of_fp32_mfma_peak"] = round(out["model_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        else:
+            out["model_executed_tflops"] = round(out["model_tflops"] * SPLIT_PRODUCTS, 1)
+            out["model_frac_of_bf16_mfma_peak"] = round(out["model_tflops"] * SPLIT_PRODUCTS / PEAK_BF16_MFMA_TFLOPS, 4)
         if full is not None:
             out["full_loop"] = {"steps": 1000, "seconds": round(full, 3), "steps_per_s": round(1000.0 * ws / full, 2),
                                 "what": "wall time of one whole 1000-step p_sample_loop via the captured graph "

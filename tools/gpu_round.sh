@@ -19,11 +19,20 @@ trace) cd /tmp && export TMPDIR=/tmp
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_train -o t -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_trace_train.log 2>&1
   cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_trace_sample -name "*.db" | head -1) > $O/${TAG}_sample_kernel_trace.txt 2>&1; python tools/rocpd_summary.py $(find $O/${TAG}_trace_train -name "*.db" | head -1) > $O/${TAG}_train_kernel_trace.txt 2>&1; head -12 $O/${TAG}_sample_kernel_trace.txt; head -25 $O/${TAG}_train_kernel_trace.txt ;;
 pmc) cd /tmp && export TMPDIR=/tmp
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 -d $O/${TAG}_pmc_sample -o p -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_sample.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $O/${TAG}_pmc_sample -o p -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_sample.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o f -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_fetch.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o w -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_write.log 2>&1
   cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_pmc_sample -name "*.db" | head -1) > $O/${TAG}_sample_pmc.txt 2>&1
   python tools/pmc_summary.py $TAG > $O/${TAG}_pmc_summary.json 2>&1; tail -25 $O/${TAG}_pmc_summary.json ;;
+pmctrain) cd /tmp && export TMPDIR=/tmp
+  # training-side counters (separate passes, kernel trace only): MFMA busy, then HBM fetch, then HBM write
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $O/${TAG}_pmct_sq -o p -- python $R/bench.py --mode train --steps 2 --warmup 2 --no-cpu-baseline > $O/${TAG}_pmct_sq.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmct_fetch -o f -- python $R/bench.py --mode train --steps 2 --warmup 2 --no-cpu-baseline > $O/${TAG}_pmct_fetch.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmct_write -o w -- python $R/bench.py --mode train --steps 2 --warmup 2 --no-cpu-baseline > $O/${TAG}_pmct_write.log 2>&1
+  cd $R; for k in sq fetch write; do python tools/rocpd_summary.py $(find $O/${TAG}_pmct_$k -name "*.db" | head -1) > $O/${TAG}_train_pmc_$k.txt 2>&1; done
+  python tools/pmc_train_summary.py $TAG > $O/${TAG}_train_pmc.txt 2>&1; head -30 $O/${TAG}_train_pmc.txt ;;
+ddp) timeout 600 python bench.py --ddp-selftest > $O/${TAG}_bench_ddp_selftest.json 2> $O/${TAG}_bench_ddp_selftest.err; tail -1 $O/${TAG}_bench_ddp_selftest.json | cut -c1-1500 ;;
+benchf32) DSC_GEMM=f32 timeout 600 python bench.py > $O/${TAG}_bench_default_f32.json 2> $O/${TAG}_bench_default_f32.err; tail -1 $O/${TAG}_bench_default_f32.json | cut -c1-600 ;;
 bf16x6) for v in 6:1 6:3 6:2 6:0; do timeout 200 python tools/gemm_bf16x6.py --k 512 --variants $v --no-extras > $O/${TAG}_gemm_bf16x6_v${v/:/_}.txt 2>&1; tail -8 $O/${TAG}_gemm_bf16x6_v${v/:/_}.txt; done
   timeout 400 python tools/gemm_bf16x6.py > $O/${TAG}_gemm_bf16x6.txt 2>&1; tail -40 $O/${TAG}_gemm_bf16x6.txt
   timeout 300 python tools/gemm_bf16x6.py --noslp --k 512 --no-extras > $O/${TAG}_gemm_bf16x6_noslp.txt 2>&1; tail -12 $O/${TAG}_gemm_bf16x6_noslp.txt ;;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-launch table of one denoiser forward plan: every step timed alone with HIP events (median of several repeats), with
-shape / FLOPs / TFLOP/s for the GEMM steps.    python tools/plan_profile.py [config] [--batch B]"""
+shape / FLOPs / TFLOP/s for the GEMM steps ("gemm*": bf16 weight planes supplied, i.e. the split-bf16 path where the shape qualifies).    python tools/plan_profile.py [config] [--batch B]"""
 import os
 import sys
 
@@ -46,13 +46,13 @@ for idx, (f, a) in enumerate(steps):
     torch.cuda.synchronize()
     us = sorted(e0.elapsed_time(e1) * 500.0 for e0, e1 in evs)[REPS // 2]
     desc, fl = f.__name__, 0.0
-    if f.__name__ == "dsc_gemm_tn_grouped_f32":
-        desc = "%s groups=%s" % (f.__name__, a[1])
+    if f.__name__ in ("dsc_gemm_tn_grouped_f32", "dsc_gemm_tn_grouped_split_f32"):
+        desc = "%s groups=%s tiles=%s splits=%s" % (f.__name__, a[1], a[3] if "split" in f.__name__ else a[2], a[4] if "split" in f.__name__ else a[3])
     if f is gemm_f or f is gn_f:
         g = a[0]._obj
         fl = 2.0 * g.m * g.n * (g.k1 + g.k2) * max(g.batch, 1)
-        desc = "%s m=%d n=%d k=%d+%d b=%d act=%d res=%d" % ("gn_gemm" if f is gn_f else "gemm", g.m, g.n, g.k1, g.k2, g.batch,
-                                                          g.act_out, 1 if g.residual else 0)
+        desc = "%s%s m=%d n=%d k=%d+%d b=%d act=%d res=%d" % ("gn_gemm" if f is gn_f else "gemm", "*" if g.w_planes else "", g.m, g.n,
+                                                            g.k1, g.k2, g.batch, g.act_out, 1 if g.residual else 0)
     rows.append((idx, desc, us, fl))
 tot = sum(r[2] for r in rows)
 print("# %s B=%d N=%d: %d launches, sum of isolated launch times %.1f us" % (name, spec["batch"], spec["objects"], len(rows), tot))

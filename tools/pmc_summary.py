@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_kernel<5, 1, 1, 4, true"
+pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_kernel<true, 2, 4, 5>"
 out = os.path.join(ROOT, "gpurun_out")
 
 
@@ -36,7 +36,9 @@ try:
     head = open(os.path.join(ROOT, "GIT_HEAD")).read().strip()
 except OSError:
     pass
-rec = {"kernel": name, "git_head": head,
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc fingerprint: bench.py only quotes a traffic file measured on the kernel sources it runs)
+rec = {"kernel": name, "git_head": head, "csrc_sha": bench.csrc_sha(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters in separate passes (tools/gpu_round.sh pmc) on "
                  "`bench.py --mode sample --steps 3 --warmup 1`; per-dispatch averages over %d launches of the kernel "
                  "(K=512 and K=1024 layers of the forward)" % nf}
@@ -51,7 +53,8 @@ if s:
     if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
         # MFMA busy is summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
         rec["mfma_busy"]["busy_fraction_per_simd"] = round((s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (s["GRBM_GUI_ACTIVE"] / 8.0), 4)
-path = os.path.join(out, "%s_gemm_gn_hbm_traffic.json" % tag)       # copy to profiles/rNN_gemm_gn_hbm_traffic.json to publish it
+path_tag = "_f32" if "gemm_kernel" in pat else ""
+path = os.path.join(out, "%s_gemm_gn_hbm_traffic%s.json" % (tag, path_tag))       # copy to profiles/rNN_gemm_gn_hbm_traffic.json to publish it
 with open(path, "w") as fh:
     json.dump(rec, fh, indent=1)
 print(json.dumps(rec, indent=1))

@@ -19,6 +19,25 @@ def main(path):
     print("%-96s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
     for r in rows:
         print("%-96s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (r[0][:96], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot))
+    # timeline: how much of the traced span the GPU spent inside kernels, and where the idle time sits
+    tl = cur.execute("select start, end, name from kernels order by start").fetchall()
+    if tl:
+        span = (max(r[1] for r in tl) - tl[0][0]) / 1e3
+        busy_end, gaps = tl[0][1], []
+        for st, en, nm in tl[1:]:
+            if st > busy_end:
+                gaps.append(((st - busy_end) / 1e3, nm))
+            busy_end = max(busy_end, en)
+        idle = sum(g for g, _ in gaps)
+        print("\n# timeline: span %.1f us, idle between kernels %.1f us (%.1f %%) in %d gaps; gaps > 100 us: %d totalling %.1f us"
+              % (span, idle, 100 * idle / span, len(gaps), sum(1 for g, _ in gaps if g > 100), sum(g for g, _ in gaps if g > 100)))
+        big = {}
+        for g, nm in gaps:
+            if g > 100:
+                k = big.setdefault(nm[:80], [0, 0.0])
+                k[0] += 1; k[1] += g
+        for nm, (c, t) in sorted(big.items(), key=lambda kv: -kv[1][1])[:8]:
+            print("#   idle before %-80s %5d x, %10.1f us" % (nm, c, t))
     try:
         pmc = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
                           "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
