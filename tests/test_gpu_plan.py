@@ -172,7 +172,8 @@ def test_train_on_batch_plan_equals_autograd_training(tmp_path, monkeypatch):
         assert abs(va - vb) <= 1e-5 * max(1.0, abs(vb))
 
 
-def test_ddp_reducer_on_rccl_world1_matches_single_process(tmp_path, monkeypatch):
+@pytest.mark.parametrize("flush", ["end", "block"])
+def test_ddp_reducer_on_rccl_world1_matches_single_process(tmp_path, monkeypatch, flush):
     """The data-parallel path on the real backend: torch.distributed 'nccl' (= RCCL) with world_size 1 and the reducer forced
     on.  Buckets must be launched from the backward's progress callback, and gradients / updated parameters must equal the
     single-process graph path (sum over one rank, 1/world = 1) up to the summation order of the weight-gradient GEMMs,
@@ -194,13 +195,16 @@ def test_ddp_reducer_on_rccl_world1_matches_single_process(tmp_path, monkeypatch
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev())
     try:
         monkeypatch.setenv("DSC_DDP_FORCE", "1")
-        for i in range(2):
+        monkeypatch.setenv("DSC_DDP_FLUSH", flush)
+        for i in range(2):                      # step 1 eager (progress callback per launch), step 2 = replay of the hipGraph segments
             torch.manual_seed(21 + i)
             train_on_batch(mb, ob, s, tcfg)
         ent = next(iter(mb._dsc_plan_runner.plans.values()))
         red = ent["reducer"]
         assert red is not None and len(red.buckets) >= 8
         assert red.launched_during_backward >= 5
+        sg = ent["graph"]
+        assert sg is not None and len(sg.segments) == len(sg.graphs) >= (5 if flush == "block" else 2), "the DDP step must be captured"
         assert _relnorm(ma._dsc_flat.G, mb._dsc_flat.G) < 2e-6
         assert _relnorm(ma._dsc_flat.P, mb._dsc_flat.P) < 2e-6
     finally:

@@ -40,4 +40,6 @@ bf16x6tn) timeout 300 python tools/gemm_tn_bf16x6.py > $O/${TAG}_gemm_tn_bf16x6.
 *) echo "unknown step $s" ;;
 esac
 done
+# the rocprofv3 databases are summarised above; gpurun only copies back <= 64 MiB
+find $O -name "*.db" -size +2M -delete 2>/dev/null
 ls $O | grep $TAG | head -40
