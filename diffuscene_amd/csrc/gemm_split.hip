@@ -30,7 +30,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BK = 32, NW = 8, T = NW * 64;
+constexpr int BK = 32;
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -95,9 +95,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch bch)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// WM x WN waves (8: one block per CU owns the LDS; 4: half the channels per block for launches that would otherwise leave CUs idle)
 template <bool GN, int WM, int WN, int RB>
-__global__ __launch_bounds__(T, 1) void gemm_split_kernel(const dsc_gemm_args p, const int ntok) {
-    static_assert(WM * WN == NW, "8 waves");
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_gemm_args p, const int ntok) {
+    constexpr int NW = WM * WN, T = 64 * NW;
+    static_assert(NW == 8 || NW == 4, "4 or 8 waves");
     constexpr int BM = 16 * RB * WM, BN = 64 * WN;       // BM = LDS rows (scenes padded to 16*RB); global rows = WM * ntok
     constexpr int B_PLANE = BN * BK * 2, X_PLANE = BM * BK * 2;
     constexpr int XA = 3 * X_PLANE, STAGE = XA + 3 * B_PLANE;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(T, 1) void gemm_split_kernel(const dsc_gemm_args p,
     constexpr int ITEMS_W = BM * 4 / NW;                 // (row, k-octet) staging items per wave
     constexpr int NIT = (ITEMS_W + 63) / 64;             // per lane
     constexpr int DUMP = (ITEMS_W % 64) ? 1024 : 0;      // where the idle lanes of a ragged item round write
-    static_assert(NIT <= RB && NIT <= 2, "the splits ride in the last NIT token blocks of a tile");
+    static_assert(NIT <= RB && NIT <= 3, "the splits ride in the last NIT token blocks of a tile");
     static_assert(2 * STAGE + DUMP <= 160 * 1024, "two stages must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + DUMP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,7 +406,7 @@ int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
     const int scenes = (a->m + ntok - 1) / ntok;
     const unsigned grid = (unsigned)(((scenes + WM - 1) / WM) * (a->n / BN));
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((gemm_split_kernel<GN, WM, WN, RB>), dim3(grid, (unsigned)a->batch), dim3(T), 0, s, *a, ntok);
+    hipLaunchKernelGGL((gemm_split_kernel<GN, WM, WN, RB>), dim3(grid, (unsigned)a->batch), dim3(64 * WM * WN), 0, s, *a, ntok);
     DSC_LAUNCH_CHECK();
     return 0;
 }
@@ -432,31 +434,46 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
     const int64_t ld_max = a->lda1 > a->lda2 ? a->lda1 : a->lda2;
     if (ld_max * 4 * 320 >= 0x7fffffffLL) return DSC_SPLIT_NOT_TAKEN;                   // 32-bit byte offsets inside a token tile
     const bool wide = (a->n % 256) == 0;
+    // A launch must fill the chip: one block per CU (two stages of operand planes own the LDS), so fewer than ~160 blocks leave more
+    // than a third of the 256 CUs idle and the f32-MFMA kernel's smaller tiles win (measured: text / M = 1536 2.6 -> 3.3 ms per
+    // step on this path, M = 10240 with 128 eight-wave blocks 51 -> 58 us per launch).  4-wave blocks (half the channels) double the
+    // block count for the half-size launches.
+    constexpr long MIN_BLOCKS = 160;
     if (gn) {
         const int N = a->tokens_per_scene;
         if (N <= 16 || N > 80) return DSC_SPLIT_NOT_TAKEN;
-        if (N <= 32) return launch<true, 4, 2, 2>(a, N, s);
-        if (!wide) return DSC_SPLIT_NOT_TAKEN;
+        const long S = a->m / N;
+        if (N <= 32) {
+            if (((S + 3) / 4) * (a->n / 128) < MIN_BLOCKS) return DSC_SPLIT_NOT_TAKEN;
+            return launch<true, 4, 2, 2>(a, N, s);
+        }
+        const long b8 = wide ? ((S + 1) / 2) * (a->n / 256) : 0, b4 = ((S + 1) / 2) * (a->n / 128);
+        if (N > 64) {
+            if (b8 >= MIN_BLOCKS + 32) return launch<true, 2, 4, 5>(a, N, s);
+            if (b4 >= MIN_BLOCKS) return launch<true, 2, 2, 5>(a, N, s);
+            return DSC_SPLIT_NOT_TAKEN;
+        }
+        if (b8 < MIN_BLOCKS) return DSC_SPLIT_NOT_TAKEN;
         if (N <= 48) return launch<true, 2, 4, 3>(a, N, s);
-        if (N <= 64) return launch<true, 2, 4, 4>(a, N, s);
-        return launch<true, 2, 4, 5>(a, N, s);
+        return launch<true, 2, 4, 4>(a, N, s);
     }
-    if (a->m < 256) return DSC_SPLIT_NOT_TAKEN;          // a handful of rows: the f32 path's 64 x 64 tiles / split-K forms
-    // dense rows: tile = (16 RB WM) x (64 WN); fewest rounds of 256 CUs x tile area wins, ties to the larger tile
+    // dense rows: tile = (16 RB WM) x (64 WN); fewest rounds of 256 CUs x tile area wins, ties to the earlier (larger) tile
     struct Cand { int bm, bn, id; };
-    const Cand cands[4] = {{160, 256, 0}, {256, 128, 1}, {128, 128, 2}, {64, 256, 3}};
+    const Cand cands[5] = {{160, 256, 0}, {256, 128, 1}, {160, 128, 4}, {128, 128, 2}, {64, 256, 3}};
     int best = -1;
-    long best_cost = 0;
-    for (int i = 0; i < 4; ++i) {
+    long best_cost = 0, best_blk = 0;
+    for (int i = 0; i < 5; ++i) {
         if (cands[i].bn == 256 && !wide) continue;
         const long nblk = (long)((a->m + cands[i].bm - 1) / cands[i].bm) * (a->n / cands[i].bn) * a->batch;
         const long c = ((nblk + 255) / 256) * (long)cands[i].bm * cands[i].bn;
-        if (best < 0 || c < best_cost) { best = cands[i].id; best_cost = c; }
+        if (best < 0 || c < best_cost) { best = cands[i].id; best_cost = c; best_blk = nblk; }
     }
+    if (best_blk < MIN_BLOCKS) return DSC_SPLIT_NOT_TAKEN;
     switch (best) {
         case 0: return launch<false, 2, 4, 5>(a, 80, s);
         case 1: return launch<false, 4, 2, 4>(a, 64, s);
         case 2: return launch<false, 4, 2, 2>(a, 32, s);
+        case 4: return launch<false, 2, 2, 5>(a, 80, s);
         default: return launch<false, 2, 4, 2>(a, 32, s);
     }
 }

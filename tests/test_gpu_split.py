@@ -50,9 +50,12 @@ def test_plane_split_is_exact_and_transposable(scale):
     assert torch.equal(pv, pc)
 
 
-@pytest.mark.parametrize("m,n,k", [(20480, 512, 512), (5376, 512, 512), (1536, 1024, 512), (300, 128, 96), (777, 384, 1024),
-                                   (20480, 3072, 512), (256, 2048, 2048)])
-def test_split_gemm_plain(m, n, k, monkeypatch):
+@pytest.mark.parametrize("m,n,k,taken", [(20480, 512, 512, True), (5376, 512, 512, True), (10240, 512, 1024, True), (10240, 384, 512, True),
+                                         (1536, 1024, 512, False), (300, 128, 96, False), (40000, 128, 96, True), (20480, 3072, 512, True),
+                                         (2560, 2048, 2048, True)])
+def test_split_gemm_plain(m, n, k, taken):
+    """Dense products of every tile class (160x256, 256x128, 160x128 four-wave, 128x128, 64x256) and the launches the dispatcher leaves
+    to the exact-f32 kernel because they would not fill the chip (`taken` False: bit-identical to the f32 path)."""
     from diffuscene_amd import ops
     a, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=0.1), rnd(n, seed=3)
     ad, wd, bd = a.to(dev()), w.to(dev()), b.to(dev())
@@ -64,14 +67,14 @@ def test_split_gemm_plain(m, n, k, monkeypatch):
     # same rounding-noise class as the exact-f32 kernel, whose own rms moves by 30 % with its tile's summation order (measured:
     # 0.8 .. 1.4 x the f32 kernel's at K >= 128; 2 x at K = 96 where both are ~1e-7)
     assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
-    assert not torch.equal(y, y32), "the split path did not take this launch (results are bit-identical to the f32 kernel)"
+    assert torch.equal(y, y32) != taken, "dispatch: split path %s this launch" % ("did not take" if taken else "took")
 
 
 @pytest.mark.parametrize("act_out", [0, 1, 2])
 def test_split_gemm_two_segments_residual_activation(act_out):
     """torch.cat of a skip connection = second K segment (own row stride), fused GELU / SiLU, residual, ragged M."""
     from diffuscene_amd import ops
-    m, n = 2000, 512
+    m, n = 10001, 512
     wide = rnd(m, 1536, seed=4)                      # a1 = a column slice of a wider buffer: lda1 != lda2
     a1, a2 = wide[:, 512:1024], rnd(m, 512, seed=5)
     w, b, r = rnd(n, 1024, seed=6, scale=0.05), rnd(n, seed=7), rnd(m, n, seed=8)
@@ -108,11 +111,12 @@ def _gn_ref(a, w, b, gamma, beta, N, ss, mode, res, idx=None):
     return z, (y + res.double() if res is not None else y)
 
 
-@pytest.mark.parametrize("B,N,mode", [(256, 80, 2), (64, 80, 4), (37, 80, 1), (16, 72, 3), (33, 64, 2), (40, 50, 3), (128, 21, 2),
-                                      (19, 32, 1), (50, 17, 0), (24, 40, 4)])
+@pytest.mark.parametrize("B,N,mode", [(256, 80, 2), (128, 80, 4), (100, 72, 1), (250, 66, 3), (320, 64, 2), (330, 48, 3), (256, 21, 2),
+                                      (170, 32, 1), (200, 17, 0), (336, 40, 4)])
 def test_split_gemm_groupnorm_block(B, N, mode):
     """Block.forward in one launch on the split path: every conditioning mode, scene lengths of every RB class (17..80), the saved
-    pre-activation, residual; against f64 and next to the exact-f32 kernel."""
+    pre-activation, residual; against f64 and next to the exact-f32 kernel.  Batches are large enough for the dispatcher to take
+    the split path (>= 160 blocks): 8-wave tiles at 256 scenes of 80, the 4-wave tile at 100 .. 128 scenes."""
     from diffuscene_amd import ops
     M, n, k = B * N, 512, 512
     a, w, b = rnd(M, k, seed=11), rnd(n, k, seed=12, scale=0.08), rnd(n, seed=13)
