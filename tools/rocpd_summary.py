@@ -38,6 +38,20 @@ def main(path):
                 k[0] += 1; k[1] += g
         for nm, (c, t) in sorted(big.items(), key=lambda kv: -kv[1][1])[:8]:
             print("#   idle before %-80s %5d x, %10.1f us" % (nm, c, t))
+    # steady-state steps: intervals between consecutive ends of a once-per-step kernel (the Adam sweep of a training step)
+    marks = [r[1] for r in tl if "adam_kernel" in r[2]] if tl else []
+    if len(marks) >= 3:
+        print("\n# per-step accounting (step = interval between consecutive adam_kernel ends; last %d steps)" % min(len(marks) - 1, 4))
+        for a, b in list(zip(marks, marks[1:]))[-4:]:
+            ks = [(st, en, nm) for st, en, nm in tl if st >= a and en <= b]
+            busy = sum(en - st for st, en, _ in ks) / 1e3
+            gaps = sorted(((ks[i + 1][0] - ks[i][1]) / 1e3, ks[i + 1][2][:60]) for i in range(len(ks) - 1))
+            pos = [g for g, _ in gaps if g > 0]
+            print("#   span %.1f us, %d kernels, in-kernel %.1f us, between kernels %.1f us (median gap %.2f us, gaps > 20 us: %d = %.1f us)"
+                  % ((b - a) / 1e3, len(ks), busy, sum(pos), pos[len(pos) // 2] if pos else 0.0, sum(1 for g in pos if g > 20),
+                     sum(g for g in pos if g > 20)))
+            for g_, nm in gaps[-4:][::-1]:
+                print("#       %.1f us before %s" % (g_, nm))
     try:
         pmc = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
                           "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
