@@ -429,14 +429,25 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
         load_items(0);
 #pragma unroll
         for (int u = 0; u < NIT; ++u) store_item(u, smem);
+        // attribution probes (WRONG results, timing only), bits of p.act: 64 no split + plane writes, 128 token fragments read once,
+        // 256 no weight DMA, 512 weight fragments read once, 1024 no block barrier, 2048 no token-row loads
+        const bool pr_nosplit = p.act & 64, pr_xonce = p.act & 128, pr_nodma = p.act & 256, pr_wonce = p.act & 512,
+                   pr_nobar = p.act & 1024, pr_noload = p.act & 2048;
+        bf16x8 wf[4][3], xf[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[0][pl] = xf[1][pl] = *(const bf16x8*)(smem + pl * X_PLANE + xoff[0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(smem + woff[j] + pl * B_PLANE);
         for (int kt = 0; kt < KT; ++kt) {
             __builtin_amdgcn_s_waitcnt(0x0070);              // my DMA chunks and my plane writes of tile kt are done
-            __syncthreads();                                 // everyone's are; nobody reads the other stage any more
+            if (!pr_nobar) __syncthreads();                  // everyone's are; nobody reads the other stage any more
             char* cur = smem + (kt & 1) * STAGE;
             char* nxt = smem + ((kt + 1) & 1) * STAGE;
             const int kn = min(kt + 1, KT - 1);              // the tail re-stages the last tile (no branch in the loop)
-            dma_tile(kn, nxt);
-            load_items(kn);
+            if (!pr_nodma) dma_tile(kn, nxt);
+            if (!pr_noload) load_items(kn);
 #ifdef RES_WARM
             // pull the residual tile (BM rows x BN f32 = 128-byte lines) towards L2 / MALL under the K loop: one dead 4-byte load per
             // line, a few lines per thread, spread over the first K tiles -- the epilogue's residual read then no longer joins the
@@ -456,17 +467,20 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                 }
             }
 #endif
-            bf16x8 wf[4][3], xf[2][3];
+            if (!pr_xonce) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *(const bf16x8*)(cur + pl * X_PLANE + xoff[0]);
+                for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *(const bf16x8*)(cur + pl * X_PLANE + xoff[0]);
+            }
+            if (!pr_wonce) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(cur + woff[j] + pl * B_PLANE);
+                    for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *(const bf16x8*)(cur + woff[j] + pl * B_PLANE);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                if (i + 1 < RB) {
+                if (i + 1 < RB && !pr_xonce) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) xf[(i + 1) & 1][pl] = *(const bf16x8*)(cur + pl * X_PLANE + xoff[i + 1]);
                 }
@@ -475,7 +489,7 @@ __global__ __launch_bounds__(T, 1) void gemm_bf16_split_kernel(const Args p) {
                     __builtin_amdgcn_s_waitcnt(0x0f70);      // the staged f32 rows (and the weight DMA) of the next tile have arrived
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (i >= RB - NIT) store_item(i - (RB - NIT), nxt);
+                if (i >= RB - NIT && !pr_nosplit) store_item(i - (RB - NIT), nxt);
                 mma_block(wf, xf[i & 1][0], xf[i & 1][1], xf[i & 1][2], acc[i]);
                 // MFMA first, then the fragment reads of the next block, then the split (2 VALU per MFMA) and its 3 LDS writes
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

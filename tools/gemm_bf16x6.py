@@ -142,20 +142,31 @@ def main():
             print("K=%d  bf16 split products=%d pipe=%d   max %.2e  rms %.2e" % ((K, v[0], v[1]) + err(outs[v])), flush=True)
 
         # 3a. attribution probes of the second generation (wrong results on purpose): which stream's latency the K loop waits for
-        if FM and "--probes" in sys.argv:
+        if "--probes" in sys.argv:
             o_ = torch.zeros(M, NOUT, device=dev)
-            for name, act in (("product form", 0), ("token rows from K tile 0 only", 64), ("weight fragments from K tile 0 only", 256),
-                              ("both", 320)):
+            plist = ((("product form", 0), ("token rows from K tile 0 only", 64), ("weight fragments from K tile 0 only", 256), ("both", 320))
+                     if FM else
+                     (("product form", 0), ("no split, no plane writes", 64), ("token fragments read once", 128), ("no weight DMA", 256),
+                      ("weight fragments read once", 512), ("no block barrier", 1024), ("no token-row loads", 2048),
+                      ("no LDS fragment reads at all", 128 + 512), ("no staging at all (DMA, loads, split)", 64 + 256 + 2048),
+                      ("MFMAs + barrier only", 64 + 128 + 256 + 512 + 2048), ("MFMAs only", 64 + 128 + 256 + 512 + 1024 + 2048)))
+            for name, act in plist:
                 for v in [v for v in variants if v[0] == 6]:
-                    for _ in range(100):
-                        launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], act=act, stream=s)
+                    g_ = torch.cuda.CUDAGraph()                  # graph of 50 launches: no host gaps, sustained clocks
+                    launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], act=act, stream=ops.stream_ptr())
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g_):
+                        for _ in range(50):
+                            launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], act=act, stream=ops.stream_ptr())
+                    for _ in range(20):
+                        g_.replay()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(50):
-                        launch6(x, planes, b, o_, M, NOUT, K, 6, v[1], act=act, stream=s)
+                    for _ in range(20):
+                        g_.replay()
                     e1.record()
                     torch.cuda.synchronize()
-                    print("K=%d probe pipe=%d %-40s %.1f us" % (K, v[1], name, e0.elapsed_time(e1) * 20.0), flush=True)
+                    print("K=%d probe pipe=%d %-44s %.1f us" % (K, v[1], name, e0.elapsed_time(e1)), flush=True)
 
         # 3c. sustained rate: every kernel alone for ~0.3 s (the power management averages over milliseconds: a 10-launch burst
         #     between other kernels can run above the sustained clock).  Launches go through a captured graph of 50 (no host gaps).
