@@ -657,119 +657,7 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_kernel(const GnBwdArgs p) {
     }
 }
 
-// Same kernel with 16-byte lanes: thread = (4 consecutive channels, every 16th token); a wave moves 4 token rows x 256 B
-// per instruction (4x fewer vector-memory instructions than the scalar form above).  Used when every operand is 16-byte
-// aligned with leading dimensions that are multiples of 4.
-__global__ __launch_bounds__(256) void gn_silu_bwd_v4_kernel(const GnBwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float gnb_cache[];          // [2][N][64]
-    __shared__ float red[4];
-    __shared__ float csum[5][4][64];
-    const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
-    const int cq = threadIdx.x & 15, tr = threadIdx.x >> 4;                     // channel quad, token lane (0..15)
-    const int wave = threadIdx.x >> 6;
-    const int c = g * 64 + cq * 4;
-    const int N = p.n_tok;
-    const long tok0 = (long)b * N;
-    const float inv_cnt = 1.0f / (64.0f * (float)N);
-    float* zc = gnb_cache + cq * 4;                                             // zc[j * 64]
-    float* dc = gnb_cache + (long)N * 64 + cq * 4;
-    float s = 0.f;
-    for (int j = tr; j < N; j += 16) {
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + (tok0 + j) * p.ldz + c);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dy + (tok0 + j) * p.ldy + c);
-        *reinterpret_cast<f32x4*>(zc + j * 64) = zv;
-        *reinterpret_cast<f32x4*>(dc + j * 64) = dv;
-        s += (zv[0] + zv[1]) + (zv[2] + zv[3]);
-    }
-    const float mu = block_sum(s, red) * inv_cnt;
-    s = 0.f;
-    for (int j = tr; j < N; j += 16) {
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(zc + j * 64);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = zv[e] - mu; s += d * d; }
-    }
-    const float rs = 1.0f / sqrtf(block_sum(s, red) * inv_cnt + p.eps);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
-    const float* ssb = nullptr;
-    long ss_step = 0;
-    if (p.ss) {
-        if (p.ss_mode == DSC_SS_PER_TOKEN) { ssb = p.ss + tok0 * p.ld_ss; ss_step = p.ld_ss; }
-        else if (p.ss_mode == DSC_SS_PER_SCENE) { ssb = p.ss + (long)b * p.ld_ss; ss_step = 0; }
-        else if (p.ss_mode == DSC_SS_PER_SLOT) { ssb = p.ss; ss_step = p.ld_ss; }
-    }
-    const bool dss_rows = p.dss && p.ss_mode != DSC_SS_PER_SCENE && ssb;
-    float S1 = 0.f, S2 = 0.f;
-    f32x4 Gg = {0.f, 0.f, 0.f, 0.f}, Gb = Gg, Gsc = Gg, Gsh = Gg, Gz = Gg;
-    for (int j = tr; j < N; j += 16) {
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(zc + j * 64);
-        const f32x4 dyv = *reinterpret_cast<const f32x4*>(dc + j * 64);
-        f32x4 s1 = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (ssb) {
-            const float* sr = ssb + (long)j * ss_step;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(sr + c);
-            sh = *reinterpret_cast<const f32x4*>(sr + p.C + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s1[e] = 1.0f + a[e];
-        }
-        f32x4 xh, dxh, d_sc, d_sh;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            xh[e] = (zv[e] - mu) * rs;
-            const float gh = ga[e] * xh[e] + be[e];
-            const float u = gh * s1[e] + sh[e];
-            const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
-            const float du = dyv[e] * (sig * (1.0f + u * (1.0f - sig)));
-            const float dgh = du * s1[e];
-            dxh[e] = dgh * ga[e];
-            S1 += dxh[e]; S2 += dxh[e] * xh[e];
-            Gg[e] += dgh * xh[e]; Gb[e] += dgh; Gsc[e] += du * gh; Gsh[e] += du;
-            d_sc[e] = du * gh; d_sh[e] = du;
-        }
-        if (dss_rows) {
-            *reinterpret_cast<f32x4*>(p.dss + (tok0 + j) * p.ld_dss + c) = d_sc;
-            *reinterpret_cast<f32x4*>(p.dss + (tok0 + j) * p.ld_dss + p.C + c) = d_sh;
-        }
-        *reinterpret_cast<f32x4*>(zc + j * 64) = xh;
-        *reinterpret_cast<f32x4*>(dc + j * 64) = dxh;
-    }
-    const float m1 = block_sum(S1, red) * inv_cnt;
-    const float m2 = block_sum(S2, red) * inv_cnt;
-    for (int j = tr; j < N; j += 16) {
-        const f32x4 xh = *reinterpret_cast<const f32x4*>(zc + j * 64);
-        const f32x4 dxh = *reinterpret_cast<const f32x4*>(dc + j * 64);
-        f32x4 dzv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { dzv[e] = rs * (dxh[e] - m1 - xh[e] * m2); Gz[e] += dzv[e]; }
-        *reinterpret_cast<f32x4*>(p.dz + (tok0 + j) * p.lddz + c) = dzv;
-    }
-    // per-channel sums over the 16 token lanes: lanes 16 / 32 apart inside the wave, then the 4 waves through LDS
-    auto fold = [&](f32x4 v, int slot) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = v[e];
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            if ((threadIdx.x & 63) < 16) csum[slot][wave][cq * 4 + e] = t;
-        }
-    };
-    fold(Gg, 0); fold(Gb, 1); fold(Gz, 2); fold(Gsc, 3); fold(Gsh, 4);
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int cl = threadIdx.x;
-        const long o = (long)b * p.pstride + g * 64 + cl;
-        p.dgamma_p[o] = (csum[0][0][cl] + csum[0][1][cl]) + (csum[0][2][cl] + csum[0][3][cl]);
-        p.dbeta_p[o] = (csum[1][0][cl] + csum[1][1][cl]) + (csum[1][2][cl] + csum[1][3][cl]);
-        p.dbias_p[o] = (csum[2][0][cl] + csum[2][1][cl]) + (csum[2][2][cl] + csum[2][3][cl]);
-        if (p.dss && p.ss_mode == DSC_SS_PER_SCENE) {
-            p.dss[(long)b * p.ld_dss + g * 64 + cl] = (csum[3][0][cl] + csum[3][1][cl]) + (csum[3][2][cl] + csum[3][3][cl]);
-            p.dss[(long)b * p.ld_dss + p.C + g * 64 + cl] = (csum[4][0][cl] + csum[4][1][cl]) + (csum[4][2][cl] + csum[4][3][cl]);
-        }
-    }
-}
-
-
-// Register-resident form of the 16-byte-lane kernel: a thread keeps its NIT (token, channel quad) elements of z and dy in
+// Register-resident form with 16-byte lanes (the LDS-cached 16-byte-lane kernel it replaced is in the git history): a thread keeps its NIT (token, channel quad) elements of z and dy in
 // VGPRs (N <= 16 * NIT), so no LDS cache is needed (41 KB per block at N = 80 limited the round-1 kernel to 3 blocks per CU
 // and cost four LDS passes); four block-wide reductions through an 8-entry double-buffered LDS slot (one barrier each).
 template <int NIT>
@@ -1706,9 +1594,6 @@ extern "C" int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy,
         if (!raised) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_silu_bwd_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            if (e != hipSuccess) return (int)e;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_silu_bwd_v4_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (e != hipSuccess) return (int)e;
             raised = true;
         }
