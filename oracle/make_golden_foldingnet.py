@@ -56,10 +56,53 @@ def main():
     with torch.no_grad():
         torch.manual_seed(11)
         out["recon_eval"] = model(pc)[2].numpy()
+    # ---- the same two objectives evaluated by the SAME reference module in fp64: how far the reference's own fp32 gradients are from
+    #      the exact ones (BatchNorm statistics over B*N values, max-pool arg-max routing, Chamfer arg-mins) -- the yardstick for the
+    #      tolerance of the gradient checks (tests/test_gpu_foldingnet.py)
+    def grads64(objective, clouds):
+        m64 = ref.KLAutoEncoder(latent_dim=LATENT, kl_weight=0.001).double()
+        m64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in W.synth_module_state(model, seed=3).items()})
+        m64.train()
+        torch.manual_seed(11)
+        if objective == "get_loss":
+            l64, _ = m64.get_loss({"points": clouds.double()})
+        else:
+            kl64, _, rec64 = m64(clouds.double())
+            l64 = (rec64 ** 2).mean() + kl64.mean()
+        l64.backward()
+        return {n: float(p.grad.norm()) for n, p in m64.named_parameters()}, float(l64.detach())
+
+    g64_loss, _ = grads64("get_loss", pc)
+    g64_sq, _ = grads64("recon_sq_plus_kl", pc)
     np.savez_compressed(os.path.join(GOLDEN, "foldingnet.npz"), **out)
+
+    # ---- the reference's own training shape: 32 clouds x 2048 points -> 2025-point folds (foldingnet_autoencoder.py:337-390, :425)
+    B2, N2 = 32, 2048
+    pc2 = W.synth_point_clouds(B2, N2, seed=6)
+    model.train()
+    model.zero_grad()
+    model.load_state_dict(W.synth_module_state(model, seed=3))
+    torch.manual_seed(12)
+    loss2k, ld2k = model.get_loss({"points": pc2})
+    loss2k.backward()
+    big = {"loss": [float(loss2k.detach()), float(ld2k["loss.cd"].detach()), float(ld2k["loss.kl"].detach())],
+           "get_loss": {n: float(p.grad.norm()) for n, p in model.named_parameters()}}
+    m64 = ref.KLAutoEncoder(latent_dim=LATENT, kl_weight=0.001).double()
+    m64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in W.synth_module_state(model, seed=3).items()})
+    m64.train()
+    torch.manual_seed(12)
+    l64, _ = m64.get_loss({"points": pc2.double()})
+    l64.backward()
+    big["get_loss_fp64"] = {n: float(p.grad.norm()) for n, p in m64.named_parameters()}
+    big["loss_fp64"] = float(l64.detach())
     with open(os.path.join(GOLDEN, "foldingnet_grads.json"), "w") as f:
-        json.dump({"recon_sq_plus_kl": grads, "get_loss": grads_loss,
+        json.dump({"recon_sq_plus_kl": grads, "get_loss": grads_loss, "recon_sq_plus_kl_fp64": g64_sq, "get_loss_fp64": g64_loss,
+                   "b32_n2048": big,
                    "state_dict": {k: list(v.shape) for k, v in model.state_dict().items()}}, f, indent=0)
+    worst = max(abs(grads_loss[n] - g64_loss[n]) / g64_loss[n] for n in grads_loss if g64_loss[n] > 1e-4 * max(g64_loss.values()))
+    worst2 = max(abs(big["get_loss"][n] - big["get_loss_fp64"][n]) / big["get_loss_fp64"][n] for n in big["get_loss"]
+                 if big["get_loss_fp64"][n] > 1e-4 * max(big["get_loss_fp64"].values()))
+    print("reference fp32 vs fp64 gradient norms: worst relative difference %.3g (B=4, N=256), %.3g (B=32, N=2048)" % (worst, worst2))
     print("wrote foldingnet.npz", {k: v.shape for k, v in out.items()})
 
 

@@ -1,7 +1,12 @@
 """FoldingNet KL auto-encoder on the HIP kernels vs the REAL reference (tests/golden/foldingnet.npz, produced by
 oracle/make_golden_foldingnet.py from scene_synthesis/networks/foldingnet_autoencoder.py with the same seeded weights and
 clouds).  Tolerances: 1e-4 relative on activations / losses (the north-star tolerance), 2e-3 on gradient norms and 1e-3 relative
-L2 on whole gradient tensors (fp32 BatchNorm statistics + arg-max routing on both sides)."""
+L2 on whole gradient tensors.  Why gradients are not held to 1e-4: the network routes gradients through discrete choices (kNN
+neighbour sets, max-pool arg-max, Chamfer arg-min) and BatchNorm statistics over B*N values, and the reference's OWN fp32 gradients
+are 3.5e-2 (B=4, N=256) / 7e-3 (B=32, N=2048) away from an fp64 evaluation of the same reference module on the same inputs
+(`*_fp64` entries of tests/golden/foldingnet_grads.json, oracle/make_golden_foldingnet.py; asserted below) -- 2e-3 against the fp32
+reference is 17x tighter than the reference's own rounding sensitivity.  The second golden is the reference's training shape,
+32 clouds x 2048 points -> 2025-point folds (foldingnet_autoencoder.py:337-390, :425)."""
 import json
 import os
 
@@ -99,3 +104,35 @@ def test_forward_loss_and_gradients_match_reference(golden_dir):
     with torch.no_grad():
         torch.manual_seed(11)
         assert rel(me(pc)[2], g["recon_eval"]) < 1e-4
+
+
+def _worst(a, b):
+    big = max(b.values())
+    return max(abs(a[n] - b[n]) / b[n] for n in a if b[n] > 1e-4 * big)
+
+
+def test_reference_fp32_gradients_are_themselves_percent_level(golden_dir):
+    """The yardstick behind the 2e-3 gradient tolerance: reference fp32 vs reference fp64, same module, same inputs."""
+    gn = json.load(open(os.path.join(golden_dir, "foldingnet_grads.json")))
+    assert 5e-3 < _worst(gn["get_loss"], gn["get_loss_fp64"]) < 1e-1
+    assert 2e-3 < _worst(gn["recon_sq_plus_kl"], gn["recon_sq_plus_kl_fp64"]) < 1e-1
+    assert 2e-3 < _worst(gn["b32_n2048"]["get_loss"], gn["b32_n2048"]["get_loss_fp64"]) < 1e-1
+
+
+@pytest.mark.gpu
+def test_training_shape_32_clouds_of_2048_points(golden_dir):
+    """get_loss (Chamfer + KL) and every gradient norm at the reference's own training shape.  Losses: 2e-4 (the reference's fp32
+    loss is 1.5e-4 from its fp64 evaluation at this size); gradient norms: within the reference's own fp32-vs-fp64 distance."""
+    big = json.load(open(os.path.join(golden_dir, "foldingnet_grads.json")))["b32_n2048"]
+    pc = W.synth_point_clouds(32, 2048, seed=6).to("cuda:0")
+    m = build()
+    torch.manual_seed(12)
+    loss, ld = m.get_loss({"points": pc})
+    loss.backward()
+    got = [float(loss.detach()), float(ld["loss.cd"].detach()), float(ld["loss.kl"].detach())]
+    for a, b in zip(got, big["loss"]):
+        assert abs(a - b) <= 2e-4 * abs(b), (got, big["loss"])
+    mine = {n: float(p.grad.norm()) for n, p in m.named_parameters()}
+    e32, e64, r = _worst(mine, big["get_loss"]), _worst(mine, big["get_loss_fp64"]), _worst(big["get_loss"], big["get_loss_fp64"])
+    print("B=32 N=2048 gradient norms: vs reference fp32 %.3g, vs reference fp64 %.3g (reference fp32 vs fp64: %.3g)" % (e32, e64, r))
+    assert e32 <= r and e64 <= 1.5 * r, (e32, e64, r)
