@@ -22,6 +22,7 @@ vocabulary on torch ops so that the plan's dataflow (buffer aliasing, accumulati
 torch.autograd without a GPU; the product never imports it.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -270,8 +271,11 @@ class HipBackend:
             per_group.append((n, kv, ldo))
         total = tile0
         if use_split:
-            # one 8-wave block per CU: cut the tokens until the long tiles make ~8 rounds of 256 blocks
-            splits = max(1, min(32, -(-8 * 256 // max(long_tiles_s, 1))))
+            # one 8-wave block per CU: cut the tokens until the long tiles make ~3 rounds of 256 blocks (measured, living80: the three
+            # grouped launches of a step 8.35 ms at 8 rounds / 7.9 ms at 3 / 8.6 ms at 2 -- fewer slabs to write and re-read against a
+            # longer tail)
+            rounds = int(os.environ.get("DSC_TN_ROUNDS", "3"))
+            splits = max(1, min(32, -(-rounds * 256 // max(long_tiles_s, 1))))
             ws_off = 0
             if splits > 1:
                 for i, (n, kv, ldo) in enumerate(per_group):
