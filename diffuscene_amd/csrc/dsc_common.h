@@ -82,4 +82,7 @@ __device__ __forceinline__ float wave_max(float v) {
 #define DSC_SPLIT_NOT_TAKEN (-1000)
 int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s);
 
+// train.hip: deterministic slab reduction of a grouped weight-gradient launch (used by both arithmetics)
+int dsc_launch_reduce_grouped(const dsc_tn_group* groups_dev, int count, int total_tiles, int splits, const float* workspace, hipStream_t s);
+
 static inline bool dsc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -24,6 +24,10 @@
 // that a lane holds 4 consecutive channels of one token: 16-byte stores.
 #include "dsc_common.h"
 
+#ifndef DSC_SPLIT_DSPREAD
+#define DSC_SPLIT_DSPREAD true
+#endif
+
 namespace dsc_split {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch bch)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // WM x WN waves (8: one block per CU owns the LDS; 4: half the channels per block for launches that would otherwise leave CUs idle)
-template <bool GN, int WM, int WN, int RB>
+template <bool GN, int WM, int WN, int RB, bool DSPREAD = DSC_SPLIT_DSPREAD>
 __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_gemm_args p, const int ntok) {
     constexpr int NW = WM * WN, T = 64 * NW;
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
@@ -146,10 +150,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
         const int plane = c / CH_PL, nrow = (c % CH_PL) * 16 + (lane >> 2);
         dvoff[i] = plane * plane_bytes + nrow * K * 2 + (((lane & 3) ^ ((nrow >> 1) & 3)) << 4);
     }
-    auto dma_tile = [&](int kt, char* stage) {
+    // chunks [i0, i1) of this wave's share of one weight tile
+    auto dma_part = [&](int kt, char* stage, auto i0c, auto i1c) {
+        constexpr int i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
         __attribute__((address_space(3))) char* lbase = (__attribute__((address_space(3))) char*)stage;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = i0; i < (i1 < NI ? i1 : NI); ++i) {
             int c = wave_u + NW * i;
             if (c >= CH) c -= CH;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -160,6 +166,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
 #endif
         }
     };
+    auto dma_tile = [&](int kt, char* stage) { dma_part(kt, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, NI>{}); };
+    // DSPREAD: the weight DMA of the next tile is issued PER chunks per token block, between the block's MFMAs, instead of all NI
+    // chunks back to back at the top of the tile (an LDS-DMA instruction holds a wave's issue for 60-185 cycles, and the two waves
+    // of a SIMD reach the top of the tile together)
+    constexpr int PER = DSPREAD ? (NI + RB - 1) / RB : NI;
 
     // accumulators: out^T blocks, lane = (token lane&15, channels 4*(lane>>4) .. +3); bias folded into the initial value
     f32x4 acc[RB][4];
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
         char* cur = smem + (kt & 1) * STAGE;
         char* nxt = smem + ((kt + 1) & 1) * STAGE;
         const int kn = min(kt + 1, KT - 1);              // the tail re-stages the last tile (no branch in the loop)
-        dma_tile(kn, nxt);
+        if constexpr (!DSPREAD) dma_tile(kn, nxt);
         load_items(kn);
         bf16x8 wf[4][3], xf[2][3];
 #pragma unroll
@@ -274,10 +285,28 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i >= RB - NIT) store_item(i - (RB - NIT), nxt);
+            if constexpr (DSPREAD) {
+                if (i * PER < NI) {
+                    if (i == 0) dma_part(kn, nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, PER>{});
+                    if (i == 1) dma_part(kn, nxt, std::integral_constant<int, PER>{}, std::integral_constant<int, 2 * PER>{});
+                    if (i == 2) dma_part(kn, nxt, std::integral_constant<int, 2 * PER>{}, std::integral_constant<int, 3 * PER>{});
+                    if (i == 3) dma_part(kn, nxt, std::integral_constant<int, 3 * PER>{}, std::integral_constant<int, 4 * PER>{});
+                    if (i == 4) dma_part(kn, nxt, std::integral_constant<int, 4 * PER>{}, std::integral_constant<int, 5 * PER>{});
+                }
+            }
             mma_block(wf, xf[i & 1][0], xf[i & 1][1], xf[i & 1][2], acc[i]);
             // MFMA first, then the fragment reads of the next block, then the split (2 VALU per MFMA) and its 3 LDS writes
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (i + 1 < RB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if constexpr (DSPREAD) {
+                if (i * PER < NI) {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            }
             if (i >= RB - NIT) {
 #pragma unroll
                 for (int q = 0; q < NMMA - 2; ++q) {

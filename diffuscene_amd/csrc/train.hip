@@ -10,7 +10,6 @@
 //   act_bwd_kernel, transpose_kernel
 // Input gradients (dA = dY . W) reuse the forward NT kernel (gemm_mfma.hip) on transposed weights.
 #include "dsc_common.h"
-#include "gemm_tn_split.h"
 
 namespace {
 
@@ -1457,58 +1456,12 @@ extern "C" int dsc_gemm_tn_f32(const float* a1, int64_t lda1, int32_t k1, const 
     return 0;
 }
 
-// The same grouped weight-gradient launch on the bf16 matrix cores (gemm_tn_split.h: operands split exactly into three bf16 pieces,
-// six products, f32 accumulation -- error vs f64 <= the f32-MFMA kernel's, ~1.6x faster).  Tiles are 256 (n) x 128 (k): groups
-// carry a second tile numbering (tile0s); the slab reduction is the f32 form's (128 x 128 tiles, tile0).
-__device__ __forceinline__ int tn_find_group_s(const dsc_tn_group* __restrict__ g, int count, int tile) {
-    int lo = 0, hi = count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (g[mid].tile0s <= tile) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-__global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int count,
-                                                                       const int splits, float* __restrict__ workspace) {
-    __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::SMEM];
-    const int tile = blockIdx.x;
-    const int gi = tn_find_group_s(groups, count, tile);
-    const dsc_tn_group g = groups[gi];
-    const int K = g.k1 + g.k2;
-    const int ktiles = (K + 127) / 128;
-    const int local = tile - g.tile0s;
-    const int split = blockIdx.y;
-    dsc_tn_split::Prob p;
-    p.a1 = g.a1; p.lda1 = g.lda1; p.k1 = g.k1; p.a2 = g.a2; p.lda2 = g.lda2; p.k2 = g.k2; p.dy = g.dy; p.ldd = g.ldd;
-    p.m = g.m; p.n = g.n; p.kvalid = g.kvalid;
-    p.chunk = ((g.m + splits - 1) / splits + 31) / 32 * 32;
-    if (splits == 1) {
-        p.out = g.out; p.ldo = g.ldo; p.bias_out = g.dbias; p.slab = 0; p.bias_slab = 0;
-    } else {
-        const long wslab = (long)g.n * g.kvalid;
-        p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
-        p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
-    }
-    dsc_tn_split::tn_split_block(p, local % ktiles, local / ktiles, split, smem);
-}
-
-extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
-                                             int32_t total_tiles_split, int32_t splits, float* workspace, int64_t workspace_floats,
-                                             int64_t workspace_needed, dsc_stream_t stream) {
-    if (!groups_dev || count < 1 || total_tiles < count || total_tiles_split < count || splits < 1 || splits > 64) return DSC_EINVAL;
-    if (splits > 1 && (!workspace || workspace_floats < workspace_needed || workspace_needed < 1)) return DSC_EINVAL;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+// slab reduction of a grouped launch (shared with gemm_tn_split.hip, whose 256 x 128 tiles write the same slab layout)
+int dsc_launch_reduce_grouped(const dsc_tn_group* groups_dev, int count, int total_tiles, int splits, const float* workspace,
+                              hipStream_t s) {
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)total_tiles_split, (unsigned)splits), dim3(512), 0, s, groups_dev,
-                       count, splits, workspace);
+    hipLaunchKernelGGL(reduce_grouped_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, groups_dev, count, splits, workspace);
     DSC_LAUNCH_CHECK();
-    if (splits > 1) {
-        DSC_CLEAR_STALE_ERROR();
-        hipLaunchKernelGGL(reduce_grouped_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, groups_dev, count, splits,
-                           workspace);
-        DSC_LAUNCH_CHECK();
-    }
     return 0;
 }
 
