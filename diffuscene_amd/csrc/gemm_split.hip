@@ -280,8 +280,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
                 for (int pl = 0; pl < 3; ++pl) xf[(i + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * X_PLANE + xoff[i + 1]);
             }
             if (i == RB - NIT) {
+                // the staged f32 rows of the next tile have arrived; with DSPREAD they are the OLDEST requests of the tile (the
+                // weight DMA chunks were issued after them and may still fly: they are only needed at the next tile's barrier)
+                constexpr int FLY = DSPREAD ? (NI < RB * PER ? NI : RB * PER) : 0;
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the staged f32 rows (and the weight DMA) of the next tile have arrived
+                __builtin_amdgcn_s_waitcnt(0x0f70 | (FLY & 15) | ((FLY >> 4) << 14));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (i >= RB - NIT) store_item(i - (RB - NIT), nxt);

@@ -169,18 +169,19 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
             }
-            if (nb == 1) {
+            if (nb >= 1) {
+                // item nb - 1 of the next step has arrived (8 loads per item, requested in item order: the younger ones may fly)
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the staged rows of the next step have arrived
+                if (nb == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 0 | (1 << 14));       // vmcnt(16)
+                if (nb == 2) __builtin_amdgcn_s_waitcnt(0x0f78);                       // vmcnt(8)
+                if (nb == 3) __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0)
                 __builtin_amdgcn_sched_barrier(0);
                 if (!more) {                          // wave-uniform: the duplicate of the last step must not enter the bias sums
 #pragma unroll
-                    for (int u = 0; u < NIT; ++u)
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ld[u][e] = 0.f;
+                    for (int e = 0; e < 8; ++e) ld[nb - 1][e] = 0.f;
                 }
+                store_item(nb - 1, nxt);
             }
-            if (nb >= 1) store_item(nb - 1, nxt);
             const bf16x8 (&d)[3] = df[nb & 1];
             // product-major over the 4 x blocks: an accumulator comes round every 4th MFMA; small terms first
 #pragma unroll
