@@ -278,7 +278,9 @@ def roofline_dominant_kernel(plan, N, config_name):
     traffic, traffic_src = None, None
     here = csrc_sha()
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_gn_hbm_traffic*.json")), reverse=True):
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_gn_hbm_traffic*.json")), reverse=True) + \
+        sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "r*_gemm_gn_hbm_traffic*.json")), reverse=True)   # same gpurun call: pmc ran first
+    for path in cands:
         with open(path) as f:
             rec = json.load(f)
         if M != 20480 or rec.get("csrc_sha") != here or ("gemm_split" in (rec.get("kernel") or "")) != split:

@@ -14,6 +14,8 @@ tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/${TAG}_tests.log 2>&
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -1 $O/${TAG}_smoke.log ;;
 bench) timeout 600 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -1 $O/${TAG}_bench_default.json | cut -c1-600 ;;
 benchall) for c in bedroom21 text complete arrange; do timeout 400 python bench.py --config $c > $O/${TAG}_bench_$c.json 2> $O/${TAG}_bench_$c.err; tail -1 $O/${TAG}_bench_$c.json | cut -c1-300; done ;;
+gemmbench) timeout 300 python tools/gemm_split_bench.py > $O/${TAG}_gemm_split_bench.txt 2>&1; tail -9 $O/${TAG}_gemm_split_bench.txt ;;
+profile) timeout 300 python tools/plan_profile.py living80 > $O/${TAG}_plan_profile_sample_living80.txt 2>&1; timeout 300 python tools/plan_profile.py living80 --train > $O/${TAG}_plan_profile_train_living80.txt 2>&1; grep -A 12 aggregated $O/${TAG}_plan_profile_train_living80.txt | cut -c1-150 ;;
 trace) cd /tmp && export TMPDIR=/tmp
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_sample -o s -- python $R/bench.py --mode sample --steps 20 --warmup 3 --no-cpu-baseline --no-full-loop > $O/${TAG}_trace_sample.log 2>&1
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_train -o t -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_trace_train.log 2>&1
