@@ -283,7 +283,8 @@ def roofline_dominant_kernel(plan, N, config_name):
     for path in cands:
         with open(path) as f:
             rec = json.load(f)
-        if M != 20480 or rec.get("csrc_sha") != here or ("gemm_split" in (rec.get("kernel") or "")) != split:
+        if (M != 20480 or rec.get("csrc_sha") != here or "hbm_bytes_per_launch" not in rec
+                or ("gemm_split" in (rec.get("kernel") or "")) != split):
             continue
         traffic = round(rec["hbm_bytes_per_launch"])
         traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; csrc %s, git %s; per-launch average over the K=512 " \

@@ -173,8 +173,10 @@ def test_graph_replay_equals_eager_and_golden(golden_dir):
 
 
 def test_two_chain_graph_equals_eager_large_batch(monkeypatch):
-    """DSC_CHAINS=2: B=128 runs the captured step as two independent 64-scene chains on two streams; the result must
-    equal the single-chain eager loop bit for bit."""
+    """DSC_CHAINS=2: B=128 runs the captured step as two independent 64-scene chains on two streams.  With the exact-f32 arithmetic
+    (DSC_GEMM=f32) the result equals the single-chain eager loop bit for bit; with the split-bf16 arithmetic the dispatcher picks
+    the kernel by launch size (a 64-scene chain leaves some products on the f32-MFMA kernel that the 128-scene launch runs on the
+    bf16 pipe), so the two agree to rounding instead."""
     from diffuscene_amd.sampler import _chains_for
     monkeypatch.setenv("DSC_CHAINS", "2")
     assert _chains_for(128) == 2 and _chains_for(2) == 1
@@ -186,7 +188,9 @@ def test_two_chain_graph_equals_eager_large_batch(monkeypatch):
     with torch.no_grad():
         eager = diff.gen_samples((B, N, C), dev(), condition=cond, noise_fn=_replay(seq), graph=False)
         graph = diff.gen_samples((B, N, C), dev(), condition=cond, noise_fn=_replay(seq), graph=True)
-    assert torch.equal(eager, graph)
+    if os.environ.get("DSC_GEMM", "split") == "f32":
+        assert torch.equal(eager, graph)
+    assert rel(graph, eager) < 1e-5
 
 
 def test_graph_completion_text_arrange_match_reference(golden_dir):
