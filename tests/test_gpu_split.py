@@ -66,7 +66,7 @@ def test_split_gemm_plain(m, n, k, taken):
     y = ops.gemm(ad, wd, bd, w_planes=pl)
     y32 = ops.gemm(ad, wd, bd)
     ref = a.double() @ w.double().T + b.double()
-    assert rel(y, ref) < 2e-6, (m, n, k, rel(y, ref))
+    assert rel(y, ref) < 2e-6 * max(1.0, k / 1024), (m, n, k, rel(y, ref))     # (the exact-f32 kernel itself reaches 2.1e-6 at K = 2048)
     # same rounding-noise class as the exact-f32 kernel, whose own rms moves by 30 % with its tile's summation order (measured:
     # 0.8 .. 1.4 x the f32 kernel's at K >= 128; 2 x at K = 96 where both are ~1e-7)
     assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
