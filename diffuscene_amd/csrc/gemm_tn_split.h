@@ -106,21 +106,19 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
     const bool do_bias = p.bias_out != nullptr && it == 0;
     float bsum[NIT] = {0.f, 0.f, 0.f};
     float ld[NIT][8];
-    auto load_items = [&](int step) {
+    auto load_item = [&](int u, int step) {
         const long mb = m_begin + (long)step * BMS;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int u = 0; u < NIT; ++u)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                ld[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isdy[u] ? rdy : rx, ivoff[u],
-                                                                                           (int)((mb + e) * (isdy[u] ? p.ldd : ldx) * 4), 0));
+        for (int e = 0; e < 8; ++e)
+            ld[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isdy[u] ? rdy : rx, ivoff[u],
+                                                                                       (int)((mb + e) * (isdy[u] ? p.ldd : ldx) * 4), 0));
 #else
         (void)mb;
 #endif
     };
-    auto store_item = [&](int u, char* stage) {
-        if (do_bias && isdy[u]) bsum[u] += ((ld[u][0] + ld[u][1]) + (ld[u][2] + ld[u][3])) + ((ld[u][4] + ld[u][5]) + (ld[u][6] + ld[u][7]));
+    auto store_item = [&](int u, char* stage, bool count) {
+        if (do_bias && isdy[u] && count) bsum[u] += ((ld[u][0] + ld[u][1]) + (ld[u][2] + ld[u][3])) + ((ld[u][4] + ld[u][5]) + (ld[u][6] + ld[u][7]));
         bf16x8 a, b, c;
         split8(ld[u], a, b, c);
         *reinterpret_cast<bf16x8*>(stage + ildso[u]) = a;
@@ -144,17 +142,23 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
 
     constexpr int NMMA = 24;                          // MFMAs per dy block (4 x blocks x 6 products)
     if (steps > 0) {
-        load_items(0);
 #pragma unroll
-        for (int u = 0; u < NIT; ++u) store_item(u, smem);
+        for (int u = 0; u < NIT; ++u) load_item(u, 0);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) store_item(u, smem, true);
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) load_item(u, steps > 1 ? 1 : 0);       // step 1: split under step 0
     }
     for (int s = 0; s < steps; ++s) {
         __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): my plane writes of step s are done
         __syncthreads();                              // everyone's are; nobody reads the other stage any more
         char* cur = smem + (s & 1) * STAGE;
         char* nxt = smem + ((s + 1) & 1) * STAGE;
-        const bool more = s + 1 < steps;              // the last step re-loads its own rows (no branch around the loads) but
-        load_items(more ? s + 1 : s);                 // does not count them into the bias gradient again (below)
+        // item u of step s + 1 (requested a whole step ago, right after the same registers were consumed) is split under dY block
+        // u + 1 of this step, and its registers immediately take the request for step s + 2: one step of load lead without a second
+        // register set.  Past the end the rows are duplicates: written to a stage nobody reads, never counted into the bias sums.
+        const bool more = s + 1 < steps;
+        const int s2 = s + 2 < steps ? s + 2 : steps - 1;
         bf16x8 xf[4][3], df[2][3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
@@ -170,17 +174,12 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
                 for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
             }
             if (nb >= 1) {
-                // item nb - 1 of the next step has arrived (8 loads per item, requested in item order: the younger ones may fly)
+                // the 8 loads of item nb - 1 are the oldest in flight; the two younger items (16 loads) may keep flying
                 __builtin_amdgcn_sched_barrier(0);
-                if (nb == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 0 | (1 << 14));       // vmcnt(16)
-                if (nb == 2) __builtin_amdgcn_s_waitcnt(0x0f78);                       // vmcnt(8)
-                if (nb == 3) __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0)
+                __builtin_amdgcn_s_waitcnt(0x0f70 | 0 | (1 << 14));                    // vmcnt(16)
                 __builtin_amdgcn_sched_barrier(0);
-                if (!more) {                          // wave-uniform: the duplicate of the last step must not enter the bias sums
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ld[nb - 1][e] = 0.f;
-                }
-                store_item(nb - 1, nxt);
+                store_item(nb - 1, nxt, more);
+                load_item(nb - 1, s2);
             }
             const bf16x8 (&d)[3] = df[nb & 1];
             // product-major over the 4 x blocks: an accumulator comes round every 4th MFMA; small terms first
@@ -206,6 +205,7 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
