@@ -65,6 +65,7 @@ class HipBackend:
         self.split = os.environ.get("DSC_GEMM", "split") != "f32"
         self._planes = {}
         self._planes_new = []
+        self.plane_bytes = 0
 
     def planes_of(self, w, rows):
         """bf16 planes of weight operand ``w`` ([n][K], rows contiguous) for a product with ``rows`` activation rows, or None."""
@@ -75,6 +76,7 @@ class HipBackend:
         ent = self._planes.get(key)
         if ent is None:
             planes = torch.empty((3,) + tuple(w.shape), device=self.device, dtype=torch.int16)
+            self.plane_bytes += planes.numel() * 2
             ent = self._planes[key] = (w, planes)
             self._planes_new.append(ent)
         return ent[1]
@@ -466,6 +468,7 @@ class TrainPlan:
         self._build()
         if hasattr(self.be, "finalize"):
             self.be.finalize()
+        self.bytes += getattr(self.be, "plane_bytes", 0)          # the plan's own bf16 weight planes count against the cache budget
 
     # ------------------------------------------------------------------------------------------------ buffers
     def new(self, rows, cols):
