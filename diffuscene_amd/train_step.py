@@ -82,8 +82,8 @@ class PlanRunner:
         distributed = self.distributed()
         # data parallel: "end" (default) keeps the single-GPU schedule -- 3 grouped weight-gradient launches, 3 graph segments, 7 of
         # the 8 buckets still leave before the last segment; measured on one GPU (bench.py --ddp-selftest,
-        # profiles/r03_bench_ddp_selftest.json): +1.5 % per step at B=256, +7 % at B=32.  "block" flushes the weight gradients every
-        # few ResnetBlocks so that buckets leave earlier (7 segments: +4.4 % / +12 %)
+        # profiles/r03_bench_ddp_selftest.json): +1.2 % per step at B=256, +4.3 % at B=32.  "block" flushes the weight gradients every
+        # few ResnetBlocks so that buckets leave earlier (7 segments: +4.3 % / +9.9 %)
         per_block = distributed and os.environ.get("DSC_DDP_FLUSH", "end") == "block"
         key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block)
         ent = self.plans.pop(key, None)
