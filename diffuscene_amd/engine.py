@@ -51,6 +51,10 @@ class Plan:
         self.pool = _Pool(dev)
         self.keep = []          # tensors / structs referenced by raw pointer
         self.steps = []         # (cfunc, args_tuple)
+        # launches whose inputs do not change during a reverse loop (sampling plans only): the context MLPs of the instance
+        # embedding and the K/V projections of the text tokens (LinearAttentionCross: denoise_net.py:283-286) depend on the
+        # conditioning alone -- they run once per loop in DenoiserEngine.prepare(), not 1000 times inside the captured step
+        self.pre_steps = []
         net = eng.net
         C_in = net.channels
         self.x_in = torch.empty((self.M, C_in), device=dev, dtype=torch.float32)
@@ -97,6 +101,21 @@ class Plan:
     def call(self, name, *args, keep=()):
         self.keep.append(keep)
         self.steps.append((_lib.fn(name), args))
+
+    def hoist(self, first):
+        """Move the launches emitted since index ``first`` out of the per-step list (sampling plans: time_table)."""
+        if self.time_table:
+            self.pre_steps += self.steps[first:]
+            del self.steps[first:]
+            return True
+        return False
+
+    def run_pre(self):
+        s = ops.stream_ptr()
+        for f, a in self.pre_steps:
+            rc = f(*a, s)
+            if rc:
+                _lib.check(rc, f.__name__)
 
     def layernorm(self, x, g, out, residual=None):
         self.call("dsc_layernorm_f32", x.data_ptr(), x.stride(0), g.data_ptr(),
@@ -172,12 +191,15 @@ class Plan:
         y = self.layernorm(x, blk.fn.norm.g, self.pool.get(M, D))
         q = self.gemm(y, att.to_q.weight, self.pool.get(M, HID))
         self.pool.put(y)
+        first = len(self.steps)
         kv = self.gemm(self.cross_in, att.to_kv.weight, self.pool.get(B * L, 2 * HID))
+        kv_is_invariant = self.hoist(first)             # sampling: computed once per loop, its buffer is never recycled
         a = self.pool.get(M, HID)
         self.call("dsc_linear_attention_f32", q.data_ptr(), HID, kv.data_ptr(), 2 * HID, kv.data_ptr() + 4 * HID,
                   2 * HID, a.data_ptr(), HID, B, N, L, float(att.scale), keep=(q, kv, a))
         self.pool.put(q)
-        self.pool.put(kv)
+        if not kv_is_invariant:
+            self.pool.put(kv)
         out = self.out_proj_ln(a, att.to_out[0], att.to_out[1].g, x)
         self.pool.put(a)
         return out
@@ -214,10 +236,12 @@ class Plan:
             t2 = self.gemm(t1, net.time_mlp[3].weight, pool.get(B, 4 * D), net.time_mlp[3].bias, act_out=ACT_SILU)
             self.ss_t = self.gemm(t2, e.t_pack_w, pool.get(B, e.t_pack_w.shape[0]), e.t_pack_b)
         if self.ctx_in is not None:
+            first = len(self.steps)
             cact = pool.get(self.ctx_in.shape[0], self.ctx_in.shape[1])       # SiLU of ResnetBlock.mlp (:181-184), once
             self.call("dsc_activation_f32", self.ctx_in.data_ptr(), cact.data_ptr(), self.ctx_in.numel(), ACT_SILU,
                       keep=(cact,))
             self.ss_c = self.gemm(cact, e.c_pack_w, pool.get(self.ctx_in.shape[0], e.c_pack_w.shape[0]), e.c_pack_b)
+            self.hoist(first)                         # sampling: the context never changes inside a reverse loop
         else:
             self.ss_c = None
         # ---- input embedding ------------------------------------------------------------------------
@@ -500,6 +524,8 @@ class DenoiserEngine:
             p.ctx_in.copy_(context[0] if ctx_mode == SS_PER_SLOT else context.reshape(B * N, ctx_dim))
         if L:
             p.cross_in.copy_(context_cross.reshape(B * L, text_dim))
+        if p.pre_steps:
+            p.run_pre()                 # loop-invariant launches of a sampling plan (after refresh(): weights and planes are current)
         return p
 
     @torch.no_grad()
