@@ -266,7 +266,7 @@ def roofline_dominant_kernel(plan, N, config_name):
     M = plan.B * N
     flops = 2.0 * M * 512 * 512
     flops_mix = sum(2.0 * M * st.n * (st.k1 + st.k2) for st in structs) / len(structs)
-    split = bool(structs[0].w_planes) and os.environ.get("DSC_GEMM", "split") != "f32" and 16 < N <= 80
+    split = _lib.fn("dsc_gemm_arithmetic")(sel512[0][0], 1) == 1       # the library's own dispatch decision for this launch
     mult, peak = (SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS) if split else (1, PEAK_FP32_MFMA_TFLOPS)
     alg = flops / (ms * 1e-3) / 1e12
     alg_mix = flops_mix / (ms_mix * 1e-3) / 1e12

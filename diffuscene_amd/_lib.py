@@ -83,6 +83,7 @@ SIGNATURES = {
     "dsc_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_gn_silu_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_split_bf16x3_f32": (C.c_int, [C.POINTER(SplitItem), C.c_int32, C.c_void_p]),
+    "dsc_gemm_arithmetic": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
     "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_splitk_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_linear_smallk_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64,

@@ -445,26 +445,26 @@ int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
 
 }  // namespace dsc_split
 
-// -> 0 / error code when the split-bf16 path took the launch, DSC_SPLIT_NOT_TAKEN when the caller should run the f32-MFMA kernel
-// (no planes, DSC_GEMM=f32 in the environment, or a shape / alignment this path does not cover).
-int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
-    using namespace dsc_split;
+// Which split kernel takes this launch: a tile id, or -1 = none (no planes, DSC_GEMM=f32 in the environment, or a shape / alignment /
+// launch size this path does not cover: the exact-f32 MFMA kernel runs).
+enum { T_GN_32 = 0, T_GN_80_W8, T_GN_80_W4, T_GN_48, T_GN_64, T_160x256, T_256x128, T_128x128, T_160x128_W4, T_64x256 };
+
+static int select_tile(const dsc_gemm_args* a, bool gn) {
     static const int mode = [] {
         const char* e = getenv("DSC_GEMM");
         return (e && e[0] == 'f') ? 0 : 1;               // DSC_GEMM=f32: exact-f32 MFMA everywhere
     }();
-    if (!mode || !a->w_planes) return DSC_SPLIT_NOT_TAKEN;
+    if (!mode || !a->w_planes) return -1;
     const int K = a->k1 + a->k2;
     // grouped launches: the weights of the problems must be the row blocks of one stacked matrix (planes [3][batch n][K])
-    if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3)))
-        return DSC_SPLIT_NOT_TAKEN;
-    if ((a->n % 128) || (K % 32)) return DSC_SPLIT_NOT_TAKEN;
-    if (!dsc_aligned16(a->w_planes) || !dsc_aligned16(a->y) || (a->ldy & 3)) return DSC_SPLIT_NOT_TAKEN;
-    if (a->bias && !dsc_aligned16(a->bias)) return DSC_SPLIT_NOT_TAKEN;
-    if (a->residual && (!dsc_aligned16(a->residual) || (a->ldr & 3))) return DSC_SPLIT_NOT_TAKEN;
-    if (3LL * a->batch * a->n * K * 2 >= 0x7fffffffLL) return DSC_SPLIT_NOT_TAKEN;      // 32-bit DMA offsets into the planes
+    if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return -1;
+    if ((a->n % 128) || (K % 32)) return -1;
+    if (!dsc_aligned16(a->w_planes) || !dsc_aligned16(a->y) || (a->ldy & 3)) return -1;
+    if (a->bias && !dsc_aligned16(a->bias)) return -1;
+    if (a->residual && (!dsc_aligned16(a->residual) || (a->ldr & 3))) return -1;
+    if (3LL * a->batch * a->n * K * 2 >= 0x7fffffffLL) return -1;                       // 32-bit DMA offsets into the planes
     const int64_t ld_max = a->lda1 > a->lda2 ? a->lda1 : a->lda2;
-    if (ld_max * 4 * 320 >= 0x7fffffffLL) return DSC_SPLIT_NOT_TAKEN;                   // 32-bit byte offsets inside a token tile
+    if (ld_max * 4 * 320 >= 0x7fffffffLL) return -1;                                    // 32-bit byte offsets inside a token tile
     const bool wide = (a->n % 256) == 0;
     // A launch must fill the chip: one block per CU (two stages of operand planes own the LDS), so fewer than ~160 blocks leave more
     // than a third of the 256 CUs idle and the f32-MFMA kernel's smaller tiles win (measured: text / M = 1536 2.6 -> 3.3 ms per
@@ -473,25 +473,17 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
     constexpr long MIN_BLOCKS = 160;
     if (gn) {
         const int N = a->tokens_per_scene;
-        if (N <= 16 || N > 80) return DSC_SPLIT_NOT_TAKEN;
+        if (N <= 16 || N > 80) return -1;
         const long S = a->m / N;
-        if (N <= 32) {
-            if (((S + 3) / 4) * (a->n / 128) < MIN_BLOCKS) return DSC_SPLIT_NOT_TAKEN;
-            return launch<true, 4, 2, 2>(a, N, s);
-        }
+        if (N <= 32) return ((S + 3) / 4) * (a->n / 128) >= MIN_BLOCKS ? T_GN_32 : -1;
         const long b8 = wide ? ((S + 1) / 2) * (a->n / 256) : 0, b4 = ((S + 1) / 2) * (a->n / 128);
-        if (N > 64) {
-            if (b8 >= MIN_BLOCKS + 32) return launch<true, 2, 4, 5>(a, N, s);
-            if (b4 >= MIN_BLOCKS) return launch<true, 2, 2, 5>(a, N, s);
-            return DSC_SPLIT_NOT_TAKEN;
-        }
-        if (b8 < MIN_BLOCKS) return DSC_SPLIT_NOT_TAKEN;
-        if (N <= 48) return launch<true, 2, 4, 3>(a, N, s);
-        return launch<true, 2, 4, 4>(a, N, s);
+        if (N > 64) return b8 >= MIN_BLOCKS + 32 ? T_GN_80_W8 : b4 >= MIN_BLOCKS ? T_GN_80_W4 : -1;
+        if (b8 < MIN_BLOCKS) return -1;
+        return N <= 48 ? T_GN_48 : T_GN_64;
     }
     // dense rows: tile = (16 RB WM) x (64 WN); fewest rounds of 256 CUs x tile area wins, ties to the earlier (larger) tile
     struct Cand { int bm, bn, id; };
-    const Cand cands[5] = {{160, 256, 0}, {256, 128, 1}, {160, 128, 4}, {128, 128, 2}, {64, 256, 3}};
+    const Cand cands[5] = {{160, 256, T_160x256}, {256, 128, T_256x128}, {160, 128, T_160x128_W4}, {128, 128, T_128x128}, {64, 256, T_64x256}};
     int best = -1;
     long best_cost = 0, best_blk = 0;
     for (int i = 0; i < 5; ++i) {
@@ -500,14 +492,32 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
         const long c = ((nblk + 255) / 256) * (long)cands[i].bm * cands[i].bn;
         if (best < 0 || c < best_cost) { best = cands[i].id; best_cost = c; best_blk = nblk; }
     }
-    if (best_blk < MIN_BLOCKS) return DSC_SPLIT_NOT_TAKEN;
-    switch (best) {
-        case 0: return launch<false, 2, 4, 5>(a, 80, s);
-        case 1: return launch<false, 4, 2, 4>(a, 64, s);
-        case 2: return launch<false, 4, 2, 2>(a, 32, s);
-        case 4: return launch<false, 2, 2, 5>(a, 80, s);
-        default: return launch<false, 2, 4, 2>(a, 32, s);
+    return best_blk >= MIN_BLOCKS ? best : -1;
+}
+
+// -> 0 / error code when the split-bf16 path took the launch, DSC_SPLIT_NOT_TAKEN when the caller should run the f32-MFMA kernel
+int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
+    using namespace dsc_split;
+    const int N = a->tokens_per_scene;
+    switch (select_tile(a, gn)) {
+        case T_GN_32: return launch<true, 4, 2, 2>(a, N, s);
+        case T_GN_80_W8: return launch<true, 2, 4, 5>(a, N, s);
+        case T_GN_80_W4: return launch<true, 2, 2, 5>(a, N, s);
+        case T_GN_48: return launch<true, 2, 4, 3>(a, N, s);
+        case T_GN_64: return launch<true, 2, 4, 4>(a, N, s);
+        case T_160x256: return launch<false, 2, 4, 5>(a, 80, s);
+        case T_256x128: return launch<false, 4, 2, 4>(a, 64, s);
+        case T_128x128: return launch<false, 4, 2, 2>(a, 32, s);
+        case T_160x128_W4: return launch<false, 2, 2, 5>(a, 80, s);
+        case T_64x256: return launch<false, 2, 4, 2>(a, 32, s);
+        default: return DSC_SPLIT_NOT_TAKEN;
     }
+}
+
+// 1: dsc_gemm_f32 (gn = 0) / dsc_gemm_gn_silu_f32 (gn != 0) would run this launch on the split-bf16 kernel; 0: exact-f32 MFMA
+extern "C" int dsc_gemm_arithmetic(const dsc_gemm_args* a, int32_t gn) {
+    if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0) return DSC_EINVAL;
+    return select_tile(a, gn != 0) >= 0 ? 1 : 0;
 }
 
 extern "C" int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream) {

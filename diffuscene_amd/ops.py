@@ -115,6 +115,11 @@ def split_planes(items, stream=None):
     return out
 
 
+def gemm_uses_split(g, gn=False):
+    """True when the library would run this launch on the split-bf16 kernel (its own dispatch decision, dsc_gemm_arithmetic)."""
+    return _lib.fn("dsc_gemm_arithmetic")(C.byref(g), 1 if gn else 0) == 1
+
+
 def run_gemm(g, gn=False, stream=None):
     name = "dsc_gemm_gn_silu_f32" if gn else "dsc_gemm_f32"
     _lib.check(_lib.fn(name)(C.byref(g), stream if stream is not None else stream_ptr()), name)

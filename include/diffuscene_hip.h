@@ -86,6 +86,10 @@ int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
 /* Exact 3-way bf16 split of f32 matrices (x = x1 + x2 + x3, round-to-nearest at each step) for dsc_gemm_args.w_planes:
  *   planes[p][r][c], p = 0..2, each plane [rows][cols] bf16 (or [cols][rows] with transpose != 0: the planes of w^T, the weight
  * operand of the input-gradient GEMM dA = dY . W).  Output columns % 8 == 0.  items: HOST array, at most DSC_WS_MAX per call. */
+/* Which arithmetic dsc_gemm_f32 (gn = 0) / dsc_gemm_gn_silu_f32 (gn != 0) would use for this launch: 1 = the split-bf16 kernel (planes
+ * supplied, shape / alignment covered, launch large enough to fill the chip, DSC_GEMM != f32), 0 = the exact-f32 MFMA kernel. */
+int dsc_gemm_arithmetic(const dsc_gemm_args* args, int32_t gn);
+
 typedef struct dsc_split_item { const float* w; int64_t ldw; int32_t rows, cols; uint16_t* planes; int32_t transpose; } dsc_split_item;
 int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream);
 

@@ -71,6 +71,8 @@ def test_split_gemm_plain(m, n, k, taken):
     # 0.8 .. 1.4 x the f32 kernel's at K >= 128; 2 x at K = 96 where both are ~1e-7)
     assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
     assert torch.equal(y, y32) != (taken and SPLIT_ON), "dispatch: split path %s this launch" % ("did not take" if taken else "took")
+    assert ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd, w_planes=pl)) == (taken and SPLIT_ON)      # the library's own answer
+    assert not ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd))
 
 
 @pytest.mark.parametrize("act_out", [0, 1, 2])
