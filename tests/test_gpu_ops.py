@@ -238,6 +238,11 @@ def test_bad_arguments_are_rejected_not_clamped():
     v = torch.zeros(512, device=dev())
     with pytest.raises(RuntimeError, match="DSC_ERANGE"):
         ops.gemm_gn_silu(x, wz, v, v, v, 200)            # more than 160 objects per scene
+    # weight planes: the split needs 8-element output rows; wrong plane shapes are caught before the launch
+    with pytest.raises(RuntimeError, match="DSC_EINVAL"):
+        ops.split_planes([(torch.zeros(64, 36, device=dev()), None, False)])
+    with pytest.raises(RuntimeError, match="w_planes"):
+        ops.make_gemm_args(x, wz, torch.zeros(400, 512, device=dev()), w_planes=torch.zeros(3, 512, 256, device=dev(), dtype=torch.int16))
 
 
 @pytest.mark.gpu
