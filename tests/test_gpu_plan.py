@@ -268,3 +268,43 @@ def test_reference_training_script_sequence_with_reference_yaml(golden_dir, tmp_
         net2, _, _ = build_network(ds.feature_size, ds.n_classes, config, str(tmp_path / "model_00000"), device=dev())
     for (k1, v1), (k2, v2) in zip(network.state_dict().items(), net2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_alternating_text_lengths_keep_their_plans_and_clean_gradients(tmp_path, monkeypatch):
+    """Text batches change the token count L from batch to batch: the plans of recently used signatures must be kept (LRU, not
+    first-in-first-out), their graphs replayed, and switching signature must not leave the previous signature's gradients behind
+    for Adam (stale gradients in G)."""
+    import copy as _copy
+    from diffuscene_amd.networks import optimizer_factory
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import train_on_batch
+    monkeypatch.setenv("DSC_PLAN_CACHE_MAX", "2")
+    m, nc = _model("text", 12, tmp_path)
+    opt = optimizer_factory({"optimizer": "Adam", "lr": 1e-4}, filter(lambda p: p.requires_grad, m.parameters()))
+    tcfg = {"training": {"max_grad_norm": 10}}
+    batches = {}
+    for L in (5, 7, 9):
+        s = _sample("text", 4, 12, nc, seed=L)
+        s["desc_bert"] = torch.randn(4, L, 768, generator=torch.Generator().manual_seed(L)).to(dev())
+        batches[L] = s
+    order = [5, 7, 5, 7, 5, 9, 5]
+    for i, L in enumerate(order):
+        torch.manual_seed(100 + i)
+        assert np.isfinite(train_on_batch(m, opt, batches[L], tcfg))
+    r = m._dsc_plan_runner
+    keys = list(r.plans)
+    assert len(keys) == 2 and [k[4] for k in keys] == [9, 5], keys          # L=7 (least recently used) went, 9 and 5 stay, 5 is newest
+    assert r.plans[keys[1]]["graph"] is not None                             # the hot signature runs from its captured graph
+    # a signature switch must not leave the previous signature's gradients behind in G
+    G = m._dsc_flat.G
+    assert float(G.abs().max()) > 0
+    r.flat.G.fill_(1.0)                                                     # poison, then force a signature switch
+    r.last_key = ("other",)
+    torch.manual_seed(1)
+    train_on_batch(m, opt, batches[5], tcfg)
+    covered = torch.zeros_like(G, dtype=torch.bool)
+    for p in m._dsc_flat.params:
+        o, n = m._dsc_flat.grad_range(p)
+        covered[o:o + n] = True
+    assert float(G[~covered].abs().max()) == 0.0                            # alignment gaps were re-zeroed with the switch
+    assert bool(torch.isfinite(G).all()) and float((G[covered] == 1.0).float().mean()) < 1e-3   # every gradient was rewritten
+    assert _copy.deepcopy(m) is not None                                     # a copied model (EMA) drops the plan caches and still copies
