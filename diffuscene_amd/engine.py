@@ -71,8 +71,10 @@ class Plan:
 
     # ---- step emitters -------------------------------------------------------------------------
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE):
-        pl = self.eng.planes_of(w) if a.shape[0] >= 256 else None
-        g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out, w_planes=pl)
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out)
+        pl = self.eng.planes_of(w) if ops.gemm_would_use_split(g) else None       # planes only for launches that will use them
+        if pl is not None:
+            g.w_planes = pl.data_ptr()
         self.keep.append((g, a, w, out, bias, a2, residual, pl))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
@@ -82,18 +84,22 @@ class Plan:
         problem (a, w, out, bias describe problem 0: views into the wider buffers)."""
         # `w` is the first row block of the stacked weights: the split path takes the planes of the whole stack
         stacked = w._base if w._base is not None else w
-        pl = self.eng.planes_of(stacked) if (a.shape[0] >= 256 and stacked.shape[0] == batch * w.shape[0]) else None
-        g = ops.make_gemm_args(a, w, out, bias, None, None, ACT_NONE, act_out, w_planes=pl)
+        g = ops.make_gemm_args(a, w, out, bias, None, None, ACT_NONE, act_out)
         g.batch, g.sa1, g.sw, g.sy, g.sbias = batch, sa, sw, sy, sbias
+        pl = self.eng.planes_of(stacked) if (stacked.shape[0] == batch * w.shape[0] and ops.gemm_would_use_split(g)) else None
+        if pl is not None:
+            g.w_planes = pl.data_ptr()
         self.keep.append((g, a, w, out, bias, pl))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, a2=None, ss=None, ss_mode=SS_NONE, residual=None):
-        pl = self.eng.planes_of(w) if 16 < self.N <= 80 else None
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5,
                                tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
-                               ss_index=self.t_in if ss_mode == SS_BY_INDEX else None, w_planes=pl)
+                               ss_index=self.t_in if ss_mode == SS_BY_INDEX else None)
+        pl = self.eng.planes_of(w) if ops.gemm_would_use_split(g, gn=True) else None
+        if pl is not None:
+            g.w_planes = pl.data_ptr()
         self.keep.append((g, a, w, out, bias, a2, residual, gamma, beta, ss, pl))
         self.steps.append((_lib.fn("dsc_gemm_gn_silu_f32"), (C.byref(g),)))
         return out

@@ -120,6 +120,18 @@ def gemm_uses_split(g, gn=False):
     return _lib.fn("dsc_gemm_arithmetic")(C.byref(g), 1 if gn else 0) == 1
 
 
+def gemm_would_use_split(g, gn=False):
+    """The same question BEFORE any planes exist: would this launch take the split path if the weight's planes were supplied?
+    (Callers skip the plane copy -- 6 bytes per weight and a split launch per weight update -- for launches that stay on the
+    exact-f32 kernel anyway: too few blocks, unsupported shape, DSC_GEMM=f32.)"""
+    saved = g.w_planes
+    g.w_planes = g.w                      # any non-null 16-byte aligned address: the decision does not read it
+    try:
+        return gemm_uses_split(g, gn)
+    finally:
+        g.w_planes = saved
+
+
 def run_gemm(g, gn=False, stream=None):
     name = "dsc_gemm_gn_silu_f32" if gn else "dsc_gemm_f32"
     _lib.check(_lib.fn(name)(C.byref(g), stream if stream is not None else stream_ptr()), name)

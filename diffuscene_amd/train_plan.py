@@ -136,15 +136,19 @@ class HipBackend:
                 g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
                 self.keep.append((g, a, w, out, bias, residual))
                 return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
-        pl = self.planes_of(w, m)
-        g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out, w_planes=pl)
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
+        pl = self.planes_of(w, m) if ops.gemm_would_use_split(g) else None          # planes only for launches that will use them
+        if pl is not None:
+            g.w_planes = pl.data_ptr()
         return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl))
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):
         from . import ops
-        pl = self.planes_of(w, a.shape[0]) if 16 < n_tok <= 80 else None
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5, tokens_per_scene=n_tok,
-                               scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE, preact=preact, w_planes=pl)
+                               scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE, preact=preact)
+        pl = self.planes_of(w, a.shape[0]) if ops.gemm_would_use_split(g, gn=True) else None
+        if pl is not None:
+            g.w_planes = pl.data_ptr()
         return self._call("dsc_gemm_gn_silu_f32", C.byref(g), keep=(g, a, w, out, bias, gamma, beta, a2, ss, residual, preact, pl))
 
     def smallk(self, x, w, bias, out, act_out=ACT_NONE):
