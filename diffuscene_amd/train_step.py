@@ -44,6 +44,10 @@ def plan_supported(model):
 class PlanRunner:
     """Plans + captured graphs of one model (one per batch signature)."""
 
+    # what lowers a plan's ops to launches: HipBackend (libdiffuscene_hip.so).  tests/ substitute the torch backend of
+    # tests/plan_sim.py to drive this runner -- plan cache, reducer, segments, broadcast -- under gloo on CPU; the product never does.
+    backend_factory = None
+
     def __init__(self, model):
         self.model = model
         self.flat = ensure_flat(model)
@@ -96,8 +100,9 @@ class PlanRunner:
             while self.plans and (len(self.plans) >= int(os.environ.get("DSC_PLAN_CACHE_MAX", "16")) or
                                   (len(self.plans) >= 2 and sum(e["plan"].bytes for e in self.plans.values()) > budget)):
                 self.plans.pop(next(iter(self.plans)))
+            backend = HipBackend(dev) if PlanRunner.backend_factory is None else PlanRunner.backend_factory(dev)
             plan = TrainPlan(model.diffusion.model, self.flat, model.diffusion.diffusion, B, N, ctx_mode, ctx_dim, L,
-                             text_dim, HipBackend(dev), per_block_grads=per_block, ctx_param=ctx_param,
+                             text_dim, backend, per_block_grads=per_block, ctx_param=ctx_param,
                              grad_scale=1.0 / (B * ws))
             ent = {"plan": plan, "graph": None, "reducer": None, "warm": 0}
             if distributed:

@@ -199,3 +199,104 @@ def test_flat_reducer_with_training_plan_matches_single_process(tmp_path):
     assert torch.allclose(plan.losses[:2], r0["losses"], rtol=1e-5, atol=1e-7)
     err = float((flat.G - r0["G"]).norm() / flat.G.norm())
     assert err < 1e-5, err
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the RUNNER path of train_on_batch under gloo, world_size 2: loss_step() itself -- parameter broadcast on the first step, plan cache,
+# FlatGradientReducer built from the plan, the eager first step, the segmented ("captured") second step, finish() -- with the torch
+# backend of tests/plan_sim.py lowering the plan.  Each rank's gradients must equal the mean of the two single-process gradients of
+# the same shards under the same seeds.
+# ---------------------------------------------------------------------------------------------------------------------
+def _wrapper_model(tmp, seed):
+    import contextlib
+    import io
+    import json
+    from oracle import weights as W
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    stats = os.path.join(tmp, "stats_w_%d.txt" % os.getpid())
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    nc, N = 22, 5
+    cfg = {"type": "diffusion_scene_layout_ddpm", "net_type": "unet1d", "point_dim": 8 + nc + 32, "latent_dim": 0,
+           "room_mask_condition": False, "sample_num_points": N, "objectness_dim": 0, "objfeat_dim": 32, "class_dim": nc,
+           "angle_dim": 2, "learnable_embedding": True, "instance_condition": True, "instance_emb_dim": 128,
+           "diffusion_kwargs": dict(schedule_type="linear", beta_start=1e-4, beta_end=0.02, time_num=1000, loss_type="mse",
+                                    model_mean_type="v", model_var_type="fixedsmall", loss_separate=True, loss_iou=True,
+                                    train_stats_file=stats),
+           "net_kwargs": dict(W.UNCOND_BEDROOM)}
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DiffusionSceneLayout_DDPM(nc + 1, None, cfg)
+    return m, nc, N
+
+
+def _shard(nc, N, lo, hi):
+    from oracle import weights as W
+    x = W.synth_scene_batch(4, N, nc, 32, seed=31)[lo:hi]
+    return {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(), "angles": x[:, :, 6:8].contiguous(),
+            "class_labels": x[:, :, 8:8 + nc].contiguous(), "objfeats_32": x[:, :, 8 + nc:].contiguous(),
+            "room_layout": torch.zeros(hi - lo, 1, 64, 64)}
+
+
+def _use_sim_backend():
+    """Swap the three HIP-only pieces for their CPU stand-ins; returns (train_step, undo)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from plan_sim import SimBackend
+    from diffuscene_amd import train_step
+    from diffuscene_amd.networks.diffusion_ddpm import GaussianDiffusion
+    saved = (train_step.PlanRunner.backend_factory, train_step.plan_supported, GaussianDiffusion.tables)
+
+    def cpu_tables(self, device):                              # (the product's tables() insists on a HIP device)
+        return {n: getattr(self, n).float() for n in self._TABLE_NAMES}
+
+    def undo():
+        train_step.PlanRunner.backend_factory, train_step.plan_supported, GaussianDiffusion.tables = saved
+    train_step.PlanRunner.backend_factory = staticmethod(lambda dev: SimBackend())
+    train_step.plan_supported = lambda model: True             # (and so does the product's plan_supported)
+    GaussianDiffusion.tables = cpu_tables
+    return train_step, undo
+
+
+def _runner_worker(rank, ws, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    torch.set_num_threads(2)
+    ts, _ = _use_sim_backend()
+    m, nc, N = _wrapper_model(tmp, seed=rank)                  # different weights per rank: the first step must broadcast rank 0's
+    s = _shard(nc, N, 2 * rank, 2 * rank + 2)
+    out = {}
+    for step in range(2):                                      # step 0: eager with per-launch progress; step 1: segment replay
+        torch.manual_seed(50 + 10 * step + rank)
+        loss, parts, ent = ts.loss_step(m, s, backward=True)
+        out["G%d" % step] = m._dsc_flat.G.clone()
+        out["loss%d" % step] = float(loss)
+    assert ent["reducer"] is not None and ent["graph"] is not None and len(ent["graph"].segments) >= 2
+    out["P"] = m._dsc_flat.P.clone()
+    torch.save(out, os.path.join(tmp, "runner_r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_loss_step_runner_path_world2_gloo(tmp_path):
+    tmp = str(tmp_path)
+    mp.spawn(_runner_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp, "runner_r0.pt")), torch.load(os.path.join(tmp, "runner_r1.pt"))
+    assert torch.equal(r0["P"], r1["P"]), "the first step must broadcast rank 0's parameters"
+    for step in range(2):
+        assert torch.equal(r0["G%d" % step], r1["G%d" % step]), "every rank must hold the same reduced gradients"
+    # single process: the two shards one after the other on rank 0's weights, same seeds; DDP gradient = their mean
+    ts, undo = _use_sim_backend()
+    try:
+        for step in range(2):
+            acc = None
+            for rank in range(2):
+                m, nc, N = _wrapper_model(tmp, seed=0)
+                torch.manual_seed(50 + 10 * step + rank)
+                ts.loss_step(m, _shard(nc, N, 2 * rank, 2 * rank + 2), backward=True)
+                g = m._dsc_flat.G.clone()
+                acc = g if acc is None else acc + g
+            want = acc / 2
+            err = float((r0["G%d" % step] - want).norm() / want.norm())
+            assert err < 1e-5, (step, err)
+    finally:
+        undo()
