@@ -35,10 +35,6 @@ pmctrain) cd /tmp && export TMPDIR=/tmp
   python tools/pmc_train_summary.py $TAG > $O/${TAG}_train_pmc.txt 2>&1; head -30 $O/${TAG}_train_pmc.txt ;;
 ddp) timeout 600 python bench.py --ddp-selftest > $O/${TAG}_bench_ddp_selftest.json 2> $O/${TAG}_bench_ddp_selftest.err; tail -1 $O/${TAG}_bench_ddp_selftest.json | cut -c1-1500 ;;
 benchf32) DSC_GEMM=f32 timeout 600 python bench.py > $O/${TAG}_bench_default_f32.json 2> $O/${TAG}_bench_default_f32.err; tail -1 $O/${TAG}_bench_default_f32.json | cut -c1-600 ;;
-bf16x6) for v in 6:1 6:3 6:2 6:0; do timeout 200 python tools/gemm_bf16x6.py --k 512 --variants $v --no-extras > $O/${TAG}_gemm_bf16x6_v${v/:/_}.txt 2>&1; tail -8 $O/${TAG}_gemm_bf16x6_v${v/:/_}.txt; done
-  timeout 400 python tools/gemm_bf16x6.py > $O/${TAG}_gemm_bf16x6.txt 2>&1; tail -40 $O/${TAG}_gemm_bf16x6.txt
-  timeout 300 python tools/gemm_bf16x6.py --noslp --k 512 --no-extras > $O/${TAG}_gemm_bf16x6_noslp.txt 2>&1; tail -12 $O/${TAG}_gemm_bf16x6_noslp.txt ;;
-bf16x6tn) timeout 300 python tools/gemm_tn_bf16x6.py > $O/${TAG}_gemm_tn_bf16x6.txt 2>&1; tail -24 $O/${TAG}_gemm_tn_bf16x6.txt ;;
 *) echo "unknown step $s" ;;
 esac
 done
