@@ -132,3 +132,53 @@ def test_plan_gradients_match_autograd(case, tmp_path):
     if case.endswith("ddp"):
         idx = [i for i in sched if i is not None]
         assert len(set(idx)) >= 4, "per-block gradients should finish buckets at different points of the backward"
+
+
+def test_plan_at_the_full_text_batch_matches_the_reference_golden(tmp_path, golden_dir):
+    """BASELINE configs[3] at its own batch (B=128, N=12, L=32): the plan on the torch backend against outputs of the REAL reference
+    (tests/golden/fullbatch.npz, oracle/make_golden_fullbatch.py): per-scene losses, the nine logged terms, 16 gradient norms and
+    the gradient that reaches the text features.  tests/test_gpu_fullbatch.py holds the HIP backend to the same file."""
+    import numpy as np
+    from plan_sim import SimBackend
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.train_plan import TrainPlan
+    from oracle.make_golden_fullbatch import fullbatch_inputs
+    import contextlib
+    import io
+    g = np.load(os.path.join(golden_dir, "fullbatch.npz"))
+    names = json.load(open(os.path.join(golden_dir, "grad_names_fullbatch.json")))["text"]
+    kw, x, t, cond, cross, noise, _ = fullbatch_inputs("text")
+    stats = os.path.join(str(tmp_path), "dataset_stats.txt")
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet1D(**kw)
+        net.load_state_dict(W.synth_state_dict(kw))
+        diff = DiffusionPoint(net, dict(objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32), time_num=1000,
+                              model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=stats).diffusion
+    flat = FlatStorage(net)
+    B, N, C = x.shape
+    L = cross.shape[1]
+    tb = {n: getattr(diff, n).float() for n in diff._TABLE_NAMES}
+    plan = TrainPlan(net, flat, diff, B, N, SS_PER_SLOT, 128, L, 512, SimBackend(), tables=tb)
+    plan.x0.copy_(x); plan.noise.copy_(noise); plan.t.copy_(t)
+    plan.ctx_in.t.copy_(cond[0])
+    plan.cross_in.t.copy_(cross.reshape(B * L, 512))
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    assert _rel(plan.losses, torch.from_numpy(g["text.losses"])) < 1e-6
+    keys = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class', 'loss.object', 'loss.objfeat', 'loss.liou',
+            'loss.bbox_iou')
+    means = plan.parts.mean(dim=0)
+    for i, k in enumerate(keys):
+        assert abs(float(means[i]) - float(g["text." + k])) <= 1e-5 * max(1.0, abs(float(g["text." + k]))), k
+    params = dict(net.named_parameters())
+    gn = np.array([float(flat.grad_view(params[k]).norm()) for k in names])
+    ref = g["text.grad_norms"]
+    assert (np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())).max() < 1e-4
+    assert abs(float(plan.d_cross.norm()) - float(g["text.d_cross_norm"])) <= 1e-4 * float(g["text.d_cross_norm"])
