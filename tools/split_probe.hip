@@ -25,6 +25,13 @@ static int g_stamp_stride = 1;
 #define PROBE_WAVES 8
 #define PROBE_TAIL (SLOTS * PROBE_WAVES * KTMAX * NST)
 
+#ifdef PROBE_NOSTAMPS            /* plain copy of the kernel (A/B of spliced variants without the stamps' waits) */
+#define PROBE_DECL
+#define PROBE_STAMP(id)
+#define PROBE_STAMP_BLOCK(i)
+#define PROBE_FLUSH
+#define PROBE_END
+#else
 #define PROBE_DECL                                                                                                             \
     unsigned long long st_[NST] = {0, 0, 0, 0, 0, 0, 0, 0};                                                                   \
     const bool st_on_ = stamps && (blockIdx.x % stamp_stride) == 0 && (int)(blockIdx.x / stamp_stride) < SLOTS;               \
@@ -46,6 +53,8 @@ static int g_stamp_stride = 1;
         d_[0] = __builtin_amdgcn_s_memrealtime() - rt0_;                                                                       \
         d_[1] = __builtin_amdgcn_s_memtime() - ct0_;                                                                           \
     }
+
+#endif
 
 #ifndef DSC_SPLIT_DSPREAD
 #define DSC_SPLIT_DSPREAD true
@@ -152,6 +161,9 @@ int main(int argc, char** argv) {
     const float t0 = sustained(0), t1 = sustained(1), t2 = sustained(2), t0b = sustained(0);
     printf("gn=%d res=%d roles=%d K=%d: product %.2f us (again %.2f), instrumented %.2f us (stamps off) %.2f us (stamps on)\n", gn, res, roles, K, t0, t0b, t1, t2);
 
+#ifdef PROBE_NOSTAMPS
+    return 0;
+#endif
     // the stamps of the LAST launch of the sustained run
     std::vector<unsigned long long> h(stamp_words);
     CK(hipMemcpy(h.data(), stamps, stamp_words * 8, hipMemcpyDeviceToHost));

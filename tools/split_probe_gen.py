@@ -28,6 +28,18 @@ def generate():
     a = src.index("namespace dsc_split {")
     b = src.index("}  // namespace dsc_split") + len("}  // namespace dsc_split")
     k = src[a:b].replace("namespace dsc_split", "namespace dsc_split_probe")
+    if "--ordered" in sys.argv:
+        # fragment reads at the top of a tile in the order the first MFMAs need them (x1 + the four w3 fragments, then x3 + w1, then
+        # x2 + w2), fenced, instead of the scheduler's order (the product's first MFMA waits for 12 of the 15 reads)
+        k = replace_once(k,
+            "        for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * X_PLANE + xoff[0]);\n"
+            "#pragma unroll\n        for (int j = 0; j < 4; ++j)\n#pragma unroll\n"
+            "            for (int pl = 0; pl < 3; ++pl) wf[j][pl] = *reinterpret_cast<const bf16x8*>(cur + woff[j] + pl * B_PLANE);\n",
+            "        for (int o = 0; o < 3; ++o) {\n"
+            "            const int xp = o == 0 ? 0 : (o == 1 ? 2 : 1), wp = o == 0 ? 2 : (o == 1 ? 0 : 1);\n"
+            "            xf[0][xp] = *reinterpret_cast<const bf16x8*>(cur + xp * X_PLANE + xoff[0]);\n"
+            "#pragma unroll\n            for (int j = 0; j < 4; ++j) wf[j][wp] = *reinterpret_cast<const bf16x8*>(cur + woff[j] + wp * B_PLANE);\n"
+            "            __builtin_amdgcn_sched_barrier(0);\n        }\n")
     # the rejected role-split form of the K loop (tools/split_probe_roles.inc) as template parameter ROLES of the copy
     k = replace_once(k, "template <bool GN, int WM, int WN, int RB, bool DSPREAD = DSC_SPLIT_DSPREAD>\n__global__",
                      "template <bool GN, int WM, int WN, int RB, bool ROLES = false, bool DSPREAD = DSC_SPLIT_DSPREAD>\n__global__")
@@ -73,7 +85,11 @@ def build():
     out = os.path.join(ROOT, "tools", "split_probe")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-I", os.path.join(ROOT, "include"),
            "-I", os.path.join(ROOT, "diffuscene_amd", "csrc"), "-I", OUT_DIR, os.path.join(ROOT, "tools", "split_probe.hip"), "-o", out,
-           "-L", os.path.join(ROOT, "diffuscene_amd"), "-ldiffuscene_hip", "-Wl,-rpath,$ORIGIN/../diffuscene_amd"] + sys.argv[1:]
+           "-L", os.path.join(ROOT, "diffuscene_amd"), "-ldiffuscene_hip", "-Wl,-rpath,$ORIGIN/../diffuscene_amd"]
+    cmd += [a for a in sys.argv[1:] if a.startswith("-D")]
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):
+            cmd[cmd.index("-o") + 1] = out = os.path.join(ROOT, "tools", a[6:])
     subprocess.check_call(cmd)
     print("built", out)
 
