@@ -45,6 +45,25 @@ class H:
 
 
 # ======================================================================================================================
+def tn_token_slices(groups, tile_n, blocks_target):
+    """Token slices of one grouped weight-gradient launch.  groups: (m tokens, n, k) per layer; tile_n x 128 output tiles;
+    blocks_target: how many blocks the long tiles should make (rounds x resident blocks).  -> (splits, m_ref).
+
+    m_ref is the token length that CARRIES the launch -- the one with the most tiles x tokens of work -- and the groups at least half
+    that long are the "long" ones whose tiles set the duration.  (Not the LONGEST group: with text conditioning the few k / v
+    projections over B x L text tokens are longer than the B x N object tokens of every other layer; slicing by them cut a text step's
+    850 bulk tiles into 32 slices of 48 tokens each -- 3.7 GB of slabs per step, 5.0 of its 12.2 ms.)  A slice is never shorter than
+    256 tokens of the bulk: below that the slab traffic outweighs the parallelism."""
+    def tiles(n, k):
+        return ((n + tile_n - 1) // tile_n) * ((k + 127) // 128)
+    work = {}
+    for m, n, k in groups:
+        work[m] = work.get(m, 0) + tiles(n, k) * m
+    m_ref = max(work, key=lambda m: (work[m], m))
+    long_tiles = sum(tiles(n, k) for m, n, k in groups if 2 * m >= m_ref)
+    return max(1, min(32, m_ref // 256, -(-blocks_target // max(long_tiles, 1)))), m_ref
+
+
 class HipBackend:
     """Lowers plan ops to (cfunc, args) launches of libdiffuscene_hip.so with pointers fixed at build time."""
 
@@ -236,19 +255,11 @@ class HipBackend:
         items = sorted(items, key=lambda it: -it["dy"].shape[0])
         arr = (self.lib.TnGroup * len(items))()
         tile0, ws_off = 0, 0
-        tile0s, long_tiles_s = 0, 0                   # 256 x 128 tile numbering of the split-bf16 form
+        tile0s = 0                                    # 256 x 128 tile numbering of the split-bf16 form
         use_split = self.split
         per_group = []
-        # the token length that carries the launch: the one with the most (256 x 128 tiles) x tokens of work.  Groups at least half
-        # that long are "long" -- their tiles set the duration and decide the number of token slices.  (Not the LONGEST group: with
-        # text conditioning the few k / v projections over B x L text tokens are longer than the B x N object tokens of every other
-        # layer, and slicing by them cut the step's 850 bulk tiles into 32 slices of 48 tokens each -- 3.7 GB of slabs per step.)
-        work = {}
-        for it in items:
-            m, n = it["dy"].shape
-            kk = it["a"].shape[1] + (it["a2"].shape[1] if it.get("a2") is not None else 0)
-            work[m] = work.get(m, 0) + ((n + 255) // 256) * ((kk + 127) // 128) * m
-        long_tiles, m_ref = 0, max(work, key=lambda m: (work[m], m))
+        shapes = [(it["dy"].shape[0], it["dy"].shape[1], it["a"].shape[1] + (it["a2"].shape[1] if it.get("a2") is not None else 0))
+                  for it in items]
         for i, it in enumerate(items):
             a, dy, out, a2, dbias = it["a"], it["dy"], it["out"], it.get("a2"), it.get("dbias")
             ap, lda = self._mat(a)
@@ -278,9 +289,6 @@ class HipBackend:
             g.tile0s = tile0s
             nts = ((n + 255) // 256) * ((k1 + k2 + 127) // 128)
             tile0s += nts
-            if 2 * m >= m_ref:
-                long_tiles += nt
-                long_tiles_s += nts
             if m * max(lda, ldd, lda2) * 4 >= 0x7fffffff:
                 use_split = False                      # 32-bit byte offsets inside an operand
             per_group.append((n, kv, ldo))
@@ -290,7 +298,7 @@ class HipBackend:
             # grouped launches of a step 8.35 ms at 8 rounds / 7.9 ms at 3 / 8.6 ms at 2 -- fewer slabs to write and re-read against a
             # longer tail)
             rounds = int(os.environ.get("DSC_TN_ROUNDS", "3"))
-            splits = max(1, min(32, m_ref // 256, -(-rounds * 256 // max(long_tiles_s, 1))))    # a slice is >= 256 tokens of the bulk
+            splits, _ = tn_token_slices(shapes, 256, rounds * 256)
             ws_off = 0
             if splits > 1:
                 for i, (n, kv, ldo) in enumerate(per_group):
@@ -306,7 +314,7 @@ class HipBackend:
                                                                     wn if splits > 1 else 0, ws_off), "dsc_gemm_tn_grouped_split_f32"))
         # the long tiles set the duration: cut the tokens until they make ~8 rounds of 2 blocks per CU (tail < 1/8); with all
         # layers of a step in one group that is 2 slabs per gradient instead of the 32 of a per-layer launch
-        splits = max(1, min(32, m_ref // 256, -(-8 * 512 // max(long_tiles, 1))))
+        splits, _ = tn_token_slices(shapes, 128, 8 * 512)
         if splits > 1:
             for i, (n, kv, ldo) in enumerate(per_group):
                 if ldo != kv:

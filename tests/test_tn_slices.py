@@ -1,0 +1,38 @@
+"""Host logic of the grouped weight-gradient launch: how many token slices (train_plan.tn_token_slices).  The rule was found wrong on the
+text configuration by a per-launch profile (profiles/r03_plan_profile_train_text.txt: splits = 32 on every launch, 5.0 of 12.2 ms) -- the
+longest group of a launch (k / v projections over B x L text tokens) decided for the 850 bulk tiles over B x N object tokens."""
+from diffuscene_amd.train_plan import tn_token_slices
+
+
+def _old_rule(groups, tile_n, target):
+    m_max = max(m for m, _, _ in groups)
+    long_tiles = sum(((n + tile_n - 1) // tile_n) * ((k + 127) // 128) for m, n, k in groups if 2 * m >= m_max)
+    return max(1, min(32, -(-target // max(long_tiles, 1))))
+
+
+def test_uniform_length_launches_choose_what_they_chose_before():
+    # the metric configuration and the B = 128 ones: every layer over the same B x N tokens, plus the per-scene time-MLP gradient
+    for m in (20480, 10240, 5376):
+        for layers in (3, 7, 44, 57):
+            groups = [(m, 512, 512)] * layers + [(m, 1024, 512)] * (layers // 4) + [(m // 80, 19456, 2048)]
+            for tile_n, target in ((256, 768), (128, 4096)):
+                got, m_ref = tn_token_slices(groups, tile_n, target)
+                assert m_ref == m
+                assert got == min(_old_rule(groups, tile_n, target), m // 256), (m, layers, tile_n)
+    assert tn_token_slices([(20480, 512, 512)] * 50, 256, 768) == (2, 20480)
+
+
+def test_text_launch_is_sliced_by_its_bulk_not_by_its_longest_group():
+    bulk = [(1536, 512, 512)] * 100 + [(1536, 1024, 512)] * 30            # B x N = 128 x 12 object tokens
+    text_side = [(4096, 256, 512)] * 9                                     # k / v projections over B x L = 128 x 32 text tokens
+    per_scene = [(128, 19456, 2048)]                                       # packed time-MLP gradient over B rows
+    groups = text_side + bulk + per_scene
+    assert _old_rule(groups, 256, 768) == 22                               # 70-token slices (the real plan: 32 slices of 48)
+    assert tn_token_slices(groups, 256, 768) == (1, 1536)                  # 1316 bulk tiles fill the chip 5 times un-sliced
+    assert tn_token_slices(groups, 128, 4096) == (2, 1536)
+
+
+def test_a_slice_is_at_least_256_tokens_of_the_bulk():
+    assert tn_token_slices([(1536, 512, 512)] * 5, 256, 768) == (6, 1536)   # 40 tiles would ask for 20 slices of 77 tokens
+    assert tn_token_slices([(160, 512, 512)] * 5, 256, 768) == (1, 160)     # tiny batches are never sliced
+    assert tn_token_slices([(20480, 512, 512)] * 2, 256, 768)[0] == 32      # the cap of the slab layout
