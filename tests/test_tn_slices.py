@@ -36,3 +36,40 @@ def test_a_slice_is_at_least_256_tokens_of_the_bulk():
     assert tn_token_slices([(1536, 512, 512)] * 5, 256, 768) == (6, 1536)   # 40 tiles would ask for 20 slices of 77 tokens
     assert tn_token_slices([(160, 512, 512)] * 5, 256, 768) == (1, 160)     # tiny batches are never sliced
     assert tn_token_slices([(20480, 512, 512)] * 2, 256, 768)[0] == 32      # the cap of the slab layout
+
+
+def test_text_training_plan_builds_on_the_host_with_short_slice_counts(tmp_path, monkeypatch):
+    """The whole training plan of BASELINE configs[3] (B=128, N=12, L=32) is BUILT on the host -- argument structs, device tables, the
+    launch list; nothing is launched, only the HIP-device check of the table-building code is bypassed -- and its three grouped
+    weight-gradient launches are cut into 2 / 6 / 3 token slices (32 each before the fix)."""
+    import contextlib
+    import io
+    import json
+    import torch
+    from oracle import weights as W
+    from diffuscene_amd import ops, train_plan
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    monkeypatch.setattr(ops, "_dev", lambda t, name=None: t)
+    chosen = []
+    real = train_plan.tn_token_slices
+
+    def spy(groups, tile_n, target):
+        r = real(groups, tile_n, target)
+        chosen.append((len(groups), r))
+        return r
+    monkeypatch.setattr(train_plan, "tn_token_slices", spy)
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    kw = dict(W.TEXT_BEDROOM)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet1D(**kw)
+        d = DiffusionPoint(net, dict(objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32), time_num=1000, model_mean_type="v",
+                           loss_separate=True, loss_iou=True, train_stats_file=str(stats)).diffusion
+    flat = FlatStorage(net)
+    tb = {n: getattr(d, n).float() for n in d._TABLE_NAMES}
+    plan = train_plan.TrainPlan(net, flat, d, 128, 12, SS_PER_SLOT, 128, 32, 512, train_plan.HipBackend(torch.device("cpu")), tables=tb)
+    assert len(plan.fwd) > 150 and len(plan.bwd) > 250
+    assert [r for _, r in chosen] == [(2, 1536), (6, 1536), (3, 1536)], chosen
