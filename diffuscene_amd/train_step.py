@@ -124,10 +124,10 @@ class PlanRunner:
             return
         red = ent["reducer"]
         eager = os.environ.get("DSC_TRAIN_GRAPH", "1") == "0"
-        if ent["graph"] is None and not eager and ent["warm"] >= 1:
+        if ent["graph"] is None and not eager and not ent.get("eager_only") and ent["warm"] >= 1:
             ent["graph"] = _capture(plan, red, self.flat.device)
             if ent["graph"] is None:
-                eager = ent["eager_only"] = True
+                eager = ent["eager_only"] = True        # sticky: a failed capture is not retried on every step
         if eager or ent.get("eager_only") or ent["graph"] is None:
             # first step (and DSC_TRAIN_GRAPH=0) eagerly: loads every code object, surfaces launch errors with a Python stack
             ent["warm"] += 1

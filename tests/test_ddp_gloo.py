@@ -300,3 +300,28 @@ def test_loss_step_runner_path_world2_gloo(tmp_path):
             assert err < 1e-5, (step, err)
     finally:
         undo()
+
+
+def test_failed_capture_is_not_retried_every_step(tmp_path, monkeypatch):
+    """after ONE failed hipGraph capture the runner stays eager (sticky ``eager_only``); it must not try to capture
+    again -- a warning, a device synchronize and a partial capture -- on every later step."""
+    ts, undo = _use_sim_backend()
+    calls = []
+
+    def failing_capture(plan, reducer, device):
+        calls.append(1)
+        return None
+    monkeypatch.setattr(ts, "_capture", failing_capture)
+    try:
+        m, nc, N = _wrapper_model(str(tmp_path), seed=0)
+        s = _shard(nc, N, 0, 2)
+        losses = []
+        for step in range(4):
+            torch.manual_seed(7)
+            loss, _, ent = ts.loss_step(m, s, backward=True)
+            losses.append(float(loss))
+        assert len(calls) == 1, "capture attempted %d times" % len(calls)
+        assert ent["graph"] is None and ent["eager_only"] is True and ent["warm"] == 4
+        assert max(losses) - min(losses) < 1e-6 * abs(losses[0])          # same seed, same (eager) launches
+    finally:
+        undo()
