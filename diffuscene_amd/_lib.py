@@ -84,6 +84,8 @@ SIGNATURES = {
     "dsc_gemm_gn_silu_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_split_bf16x3_f32": (C.c_int, [C.POINTER(SplitItem), C.c_int32, C.c_void_p]),
     "dsc_gemm_arithmetic": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
+    "dsc_get_gemm_arithmetic": (C.c_int, []),
+    "dsc_set_gemm_arithmetic": (C.c_int, [C.c_int32]),
     "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_gemm_splitk_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_linear_smallk_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64,
@@ -139,7 +141,7 @@ SIGNATURES = {
                                       c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "dsc_weight_standardize_bwd_f32": (C.c_int, [C.POINTER(WsBwdItem), C.c_int32, C.c_float, C.c_void_p]),
-    "dsc_layernorm_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
+    "dsc_layernorm_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "dsc_linear_attention_bwd_f32": (C.c_int, [c_f32p, C.c_int64] * 7 + [C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                                                           C.c_void_p]),
@@ -196,8 +198,26 @@ def load():
             raise HipLibraryMissing("symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.restype = res
         fn.argtypes = args
+    if lib.dsc_get_gemm_arithmetic() < 0:
+        raise ValueError("DSC_GEMM=%r: must be 'split' (default) or 'f32'" % os.environ.get("DSC_GEMM"))
     _lib = lib
     return lib
+
+
+def split_enabled():
+    """The library's GEMM arithmetic switch (dsc_get_gemm_arithmetic): True = split-bf16 wherever a launch qualifies, False = exact-f32
+    MFMA everywhere.  The ONLY place host code learns the arithmetic from -- nothing in the package parses DSC_GEMM."""
+    return load().dsc_get_gemm_arithmetic() == 1
+
+
+def set_gemm_arithmetic(name):
+    """Switch the arithmetic per call ('split' | 'f32'); returns the previous name.  Engines, training plans and sampling graphs are
+    keyed by the arithmetic they were built under and are rebuilt on their next use after a switch."""
+    if name not in ("split", "f32"):
+        raise ValueError("gemm arithmetic must be 'split' or 'f32', got %r" % (name,))
+    prev = "split" if split_enabled() else "f32"
+    check(load().dsc_set_gemm_arithmetic(1 if name == "split" else 0), "dsc_set_gemm_arithmetic")
+    return prev
 
 
 def check(rc, what):

@@ -23,6 +23,8 @@
 // the MFMAs of tile kt and write three bf16 planes to the other LDS stage.  The MFMA computes out^T (weights as the row operand) so
 // that a lane holds 4 consecutive channels of one token: 16-byte stores.
 #include "dsc_common.h"
+#include <atomic>
+#include <cstring>
 
 #ifndef DSC_SPLIT_DSPREAD
 #define DSC_SPLIT_DSPREAD true
@@ -449,12 +451,31 @@ int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
 // launch size this path does not cover: the exact-f32 MFMA kernel runs).
 enum { T_GN_32 = 0, T_GN_80_W8, T_GN_80_W4, T_GN_48, T_GN_64, T_160x256, T_256x128, T_128x128, T_160x128_W4, T_64x256 };
 
-static int select_tile(const dsc_gemm_args* a, bool gn) {
-    static const int mode = [] {
+// The arithmetic of the GEMM entry points -- ONE source of truth for the library and its host code (engine, training plan, bench all
+// ask dsc_get_gemm_arithmetic): 1 = split-bf16 wherever a launch qualifies (default), 0 = exact-f32 MFMA everywhere.  Initial value
+// from the environment, strictly: DSC_GEMM unset / "" / "split" -> 1, "f32" -> 0, anything else -> DSC_EINVAL (every GEMM launch
+// then fails with DSC_EINVAL instead of silently picking one).  dsc_set_gemm_arithmetic switches it per call (process-wide; launches
+// already captured in a hipGraph keep the kernels they were captured with).
+static std::atomic<int> g_gemm_arith{-1000};
+
+extern "C" int dsc_get_gemm_arithmetic(void) {
+    int m = g_gemm_arith.load(std::memory_order_relaxed);
+    if (m == -1000) {
         const char* e = getenv("DSC_GEMM");
-        return (e && e[0] == 'f') ? 0 : 1;               // DSC_GEMM=f32: exact-f32 MFMA everywhere
-    }();
-    if (!mode || !a->w_planes) return -1;
+        m = (!e || !e[0] || !strcmp(e, "split")) ? 1 : !strcmp(e, "f32") ? 0 : DSC_EINVAL;
+        g_gemm_arith.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+extern "C" int dsc_set_gemm_arithmetic(int32_t mode) {
+    if (mode != 0 && mode != 1) return DSC_EINVAL;
+    g_gemm_arith.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+static int select_tile(const dsc_gemm_args* a, bool gn) {
+    if (dsc_get_gemm_arithmetic() != 1 || !a->w_planes) return -1;
     const int K = a->k1 + a->k2;
     // grouped launches: the weights of the problems must be the row blocks of one stacked matrix (planes [3][batch n][K])
     if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return -1;
@@ -498,6 +519,7 @@ static int select_tile(const dsc_gemm_args* a, bool gn) {
 // -> 0 / error code when the split-bf16 path took the launch, DSC_SPLIT_NOT_TAKEN when the caller should run the f32-MFMA kernel
 int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
     using namespace dsc_split;
+    if (dsc_get_gemm_arithmetic() < 0) return DSC_EINVAL;                // DSC_GEMM holds an unknown value
     const int N = a->tokens_per_scene;
     switch (select_tile(a, gn)) {
         case T_GN_32: return launch<true, 4, 2, 2>(a, N, s);

@@ -838,6 +838,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                            const float* __restrict__ g,
                                                            const float* __restrict__ dy, long ldy,
                                                            float* __restrict__ dx, long lddx,
+                                                           const float* __restrict__ addend, long ldadd,
                                                            float* __restrict__ dg_partial, int m, float eps) {
     __shared__ float red[4][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -874,6 +875,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
             oa[e] = rs * (ha[e] - m1 - xa[e] * m2);
             ob[e] = rs * (hb[e] - m1 - xb[e] * m2);
+        }
+        if (addend) {                              // dx = addend + d LayerNorm: the gradient x already holds from another consumer
+            const float* ar = addend + row * ldadd;
+            oa += *reinterpret_cast<const f32x4*>(ar + lane * 4);
+            ob += *reinterpret_cast<const f32x4*>(ar + 256 + lane * 4);
         }
         float* o = dx + row * lddx;
         *reinterpret_cast<f32x4*>(o + lane * 4) = oa;
@@ -1581,15 +1587,15 @@ extern "C" int dsc_weight_standardize_bwd_f32(const dsc_ws_bwd_item* items, int3
 }
 
 extern "C" int dsc_layernorm_bwd_f32(const float* x, int64_t ldx, const float* g, const float* dy, int64_t ldy, float* dx,
-                                     int64_t lddx, float* dg_partial, int32_t partial_rows, int32_t m, int32_t d,
-                                     float eps, dsc_stream_t stream) {
+                                     int64_t lddx, const float* addend, int64_t ldadd, float* dg_partial, int32_t partial_rows,
+                                     int32_t m, int32_t d, float eps, dsc_stream_t stream) {
     if (!x || !g || !dy || !dx || !dg_partial || m < 1 || partial_rows < 1) return DSC_EINVAL;
     if (d != 512) return DSC_ERANGE;
     if (!dsc_aligned16(x) || !dsc_aligned16(g) || !dsc_aligned16(dy) || !dsc_aligned16(dx) || (ldx & 3) || (ldy & 3) ||
-        (lddx & 3)) return DSC_EALIGN;
+        (lddx & 3) || (addend && (!dsc_aligned16(addend) || (ldadd & 3)))) return DSC_EALIGN;
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(partial_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x, (long)ldx, g, dy, (long)ldy, dx, (long)lddx, dg_partial, m, eps);
+                       x, (long)ldx, g, dy, (long)ldy, dx, (long)lddx, addend, (long)ldadd, dg_partial, m, eps);
     DSC_LAUNCH_CHECK();
     return 0;
 }

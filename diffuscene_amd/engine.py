@@ -69,6 +69,17 @@ class Plan:
         self._build()
         self.tiled_steps = self.steps            # one launch per layer (bench.py times the dominant kernel from these)
 
+    def gemm_args(self):
+        """('gn' | 'plain', dsc_gemm_args) of every GEMM launch of the step, in launch order -- what tests and bench.py hand to
+        dsc_gemm_arithmetic to learn which kernel (split-bf16 / exact-f32 MFMA) each launch runs."""
+        kinds = {id(_lib.fn("dsc_gemm_gn_silu_f32")): "gn", id(_lib.fn("dsc_gemm_f32")): "plain"}
+        out = []
+        for f, a in self.steps:
+            k = kinds.get(id(f))
+            if k is not None:
+                out.append((k, a[0]._obj))            # ctypes.byref(struct) keeps the struct in ._obj
+        return out
+
     # ---- step emitters -------------------------------------------------------------------------
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE):
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out)
@@ -369,9 +380,9 @@ class DenoiserEngine:
         self.sig = None
         self.ws = {}
         # split-bf16 GEMM path (csrc/gemm_split.hip): bf16 planes of every weight a plan multiplies with, re-split by refresh()
-        # whenever the parameters change.  DSC_GEMM=f32 keeps the exact-f32 MFMA kernels everywhere (no planes are made).
-        import os
-        self.split = os.environ.get("DSC_GEMM", "split") != "f32"
+        # whenever the parameters change.  With the exact-f32 arithmetic selected (_lib.split_enabled() False: DSC_GEMM=f32 or
+        # set_gemm_arithmetic("f32")) no planes are made; Unet1D.engine() rebuilds the engine when the switch has moved since.
+        self.split = _lib.split_enabled()
         self._planes = {}
         ws_mods, t_blocks, c_blocks = [], [], []
         for rb, kind in net.resblocks_in_order():

@@ -204,7 +204,8 @@ class Unet1D(nn.Module):
 
     def engine(self, device):
         from ..engine import DenoiserEngine
-        if self._engine is None or self._engine_device != device:
+        from .._lib import split_enabled
+        if self._engine is None or self._engine_device != device or self._engine.split != split_enabled():
             self._engine = DenoiserEngine(self, device)
             self._engine_device = device
         return self._engine

@@ -436,7 +436,7 @@ def layernorm_bwd(x, g, dy, eps=1e-5):
     dx = torch.empty((M, Dd), device=x.device, dtype=torch.float32)
     nblk = min((M + 3) // 4, 512)
     part = torch.empty((nblk, Dd), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.fn("dsc_layernorm_bwd_f32")(xp, ldx, _dev(g).data_ptr(), dp, ldy, dx.data_ptr(), Dd, part.data_ptr(),
+    _lib.check(_lib.fn("dsc_layernorm_bwd_f32")(xp, ldx, _dev(g).data_ptr(), dp, ldy, dx.data_ptr(), Dd, None, 0, part.data_ptr(),
                                                 nblk, M, Dd, eps, stream_ptr()), "dsc_layernorm_bwd_f32")
     return dx, colsum(part)
 

@@ -79,9 +79,8 @@ class HipBackend:
         self.scratch = None
         self._scratch_users = []
         # split-bf16 GEMM path (csrc/gemm_split.hip): bf16 planes of every weight operand of a large product; the plan inserts the
-        # launches that refresh them (once per step and phase) -- DSC_GEMM=f32 keeps the exact-f32 MFMA kernels
-        import os
-        self.split = os.environ.get("DSC_GEMM", "split") != "f32"
+        # launches that refresh them (once per step and phase) -- the exact-f32 arithmetic (_lib.split_enabled() False) makes none
+        self.split = _lib.split_enabled()
         self._planes = {}
         self._planes_new = []
         self.plane_bytes = 0
@@ -374,12 +373,13 @@ class HipBackend:
             steps.append(self._call("dsc_weight_standardize_bwd_f32", arr, len(ws_), 1e-5, keep=(arr, ws_, gs, os_)))
         return steps
 
-    def layernorm_bwd(self, x, g, dy, dx, dg_part):
+    def layernorm_bwd(self, x, g, dy, dx, dg_part, addend=None):
         xp, ldx = self._mat(x)
         dp, ldy = self._mat(dy)
         dxp, lddx = self._mat(dx)
-        return self._call("dsc_layernorm_bwd_f32", xp, ldx, g.data_ptr(), dp, ldy, dxp, lddx, dg_part.data_ptr(),
-                          dg_part.shape[0], x.shape[0], x.shape[1], 1e-5, keep=(x, g, dy, dx, dg_part))
+        ap, lda = self._mat(addend) if addend is not None else (None, 0)
+        return self._call("dsc_layernorm_bwd_f32", xp, ldx, g.data_ptr(), dp, ldy, dxp, lddx, ap, lda, dg_part.data_ptr(),
+                          dg_part.shape[0], x.shape[0], x.shape[1], 1e-5, keep=(x, g, dy, dx, dg_part, addend))
 
     def linattn_bwd(self, q, k, v, dout, dq, dk, dv, scenes, nq, nk, scale):
         a = []
@@ -444,13 +444,18 @@ class TrainPlan:
     """Forward + loss + backward launch lists of one (B, N, conditioning) signature of one Unet1D."""
 
     def __init__(self, net, flat, diff, B, N, ctx_mode, ctx_dim, L, text_dim, backend, per_block_grads=False,
-                 ctx_param=None, tables=None, grad_scale=None):
+                 ctx_param=None, tables=None, grad_scale=None, tn_flush_floats=None):
         self.net, self.flat, self.diff = net, flat, diff
         self.B, self.N, self.M = B, N, B * N
         self.be = backend
         self.device = backend.device
         self.ctx_mode, self.ctx_dim, self.L, self.text_dim = ctx_mode, ctx_dim, L, text_dim
         self.per_block_grads = per_block_grads
+        # Single GPU (None): every weight-gradient GEMM of the step waits for ONE grouped launch at the end of the backward (nothing
+        # forces an earlier one since round 4: out-of-place LayerNorm accumulation, column-exact hazard check).  Data parallel: the
+        # pending group is launched whenever it holds this many gradient floats, so that buckets of G finish -- and their
+        # all-reduces start -- while the rest of the backward is still running (train_step.PlanRunner: a third of G -> 3 launches)
+        self.tn_flush_floats = tn_flush_floats
         self.fwd, self.bwd = [], []
         self._tape = []
         self._transposes = []
@@ -539,9 +544,22 @@ class TrainPlan:
             return
         key = t.untyped_storage().data_ptr()
         for it in self._tn_pending:
-            if it["dy"].untyped_storage().data_ptr() == key:
+            if it["dy"].untyped_storage().data_ptr() == key and self._may_overlap(t, it["dy"]):
                 self.flush_tn()
                 return
+
+    @staticmethod
+    def _may_overlap(u, v):
+        """Two views of ONE storage: False only when they are provably disjoint -- row-major 2-D views with the same row stride whose
+        column ranges do not meet (the two halves of a [M, 1024] skip-connection pair buffer: accumulating into one half must not force
+        out the weight-gradient GEMMs that read the other)."""
+        if u.dim() != 2 or v.dim() != 2 or u.stride(1) != 1 or v.stride(1) != 1 or u.stride(0) != v.stride(0):
+            return True
+        S = u.stride(0)
+        cu, cv = u.storage_offset() % S, v.storage_offset() % S
+        if cu + u.shape[1] > S or cv + v.shape[1] > S:
+            return True
+        return not (cu + u.shape[1] <= cv or cv + v.shape[1] <= cu)
 
     def g_alias(self, h, src):
         """grad(h) += src where src is a finished gradient tensor: no copy when it is the first contribution."""
@@ -575,6 +593,17 @@ class TrainPlan:
             self._guard(h.g)
             self.emit(self.be.add(h.g, tmp))
             self.n_adds += 1
+
+    def g_write_add(self, h, produce):
+        """Contribution from a kernel that can ADD the gradient ``h`` already holds while it writes its own (``produce(dst, addend)``:
+        dst = addend + contribution), OUT OF PLACE: the old buffer is only read -- weight-gradient GEMMs still pending on it need no
+        flush, other handles aliasing it keep their (complete) value -- and ``h.g`` becomes the new buffer.  No add launch."""
+        if not h.ng:
+            return
+        old = h.g
+        dst = self.new(*h.t.shape)
+        produce(dst, old)
+        h.g = dst
 
     def g_gemm(self, a, a2, dy, wt):
         """grad([a | a2]) += dy @ wt^T-layout weight (wt is [K, n]: the GEMM computes dy . wt^T)."""
@@ -624,6 +653,8 @@ class TrainPlan:
         all of them run as one grouped launch (flush_tn) instead of one M-split launch + slab reduction per layer."""
         self._tn_pending.append({"a": a, "dy": dy, "out": out, "a2": a2, "kvalid": kvalid, "dbias": dbias,
                                  "params": tuple(p for p in params if p is not None), "after": after})
+        if self.tn_flush_floats and sum(it["out"].numel() for it in self._tn_pending) >= self.tn_flush_floats:
+            self.flush_tn()
 
     def colsum_later(self, x, out, params=(), after=None):
         """out = column sums of x, deferred into the next grouped launch (flush_tn): leaves of the backward, like the weight
@@ -808,7 +839,7 @@ class TrainPlan:
             M_ = x.t.shape[0]
             nblk = min((M_ + 3) // 4, 512)
             part = self.new(nblk, x.t.shape[1])
-            self.g_write(x, lambda dst: self.emit(self.be.layernorm_bwd(x.t, g, dy, dst, part)))
+            self.g_write_add(x, lambda dst, addend: self.emit(self.be.layernorm_bwd(x.t, g, dy, dst, part, addend)))
             self.colsum_later(part, self.flat.grad_view(gain).view(-1), params=(gain,))
             if residual is not None:
                 self.g_alias(residual, dy)

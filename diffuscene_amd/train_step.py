@@ -84,12 +84,15 @@ class PlanRunner:
         from .train_plan import HipBackend, TrainPlan
         ws = self.world()
         distributed = self.distributed()
-        # data parallel: "end" (default) keeps the single-GPU schedule -- 3 grouped weight-gradient launches, 3 graph segments, 7 of
-        # the 8 buckets still leave before the last segment; measured on one GPU (bench.py --ddp-selftest,
-        # profiles/r03_bench_ddp_selftest.json): +1.2 % per step at B=256, +4.3 % at B=32.  "block" flushes the weight gradients every
-        # few ResnetBlocks so that buckets leave earlier (7 segments: +4.3 % / +9.9 %)
+        # data parallel: "end" (default) launches the pending weight-gradient group whenever it holds a third of G -- 3 grouped
+        # launches, 3+ graph segments, most buckets leave before the last segment (the single-GPU plan keeps ONE grouped launch at the
+        # end of the backward); round 3, when the single-GPU schedule itself had 3 launches, measured on one GPU (bench.py
+        # --ddp-selftest, profiles/r03_bench_ddp_selftest.json): +1.2 % per step at B=256, +4.3 % at B=32.  "block" flushes the weight
+        # gradients every few ResnetBlocks so that buckets leave earlier (7 segments: +4.3 % / +9.9 %)
         per_block = distributed and os.environ.get("DSC_DDP_FLUSH", "end") == "block"
-        key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block)
+        from ._lib import split_enabled
+        arith = split_enabled() if PlanRunner.backend_factory is None else None      # plans bake the arithmetic in (planes, TN form)
+        key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block, arith)
         ent = self.plans.pop(key, None)
         if ent is None:
             model = self.model
@@ -103,7 +106,8 @@ class PlanRunner:
             backend = HipBackend(dev) if PlanRunner.backend_factory is None else PlanRunner.backend_factory(dev)
             plan = TrainPlan(model.diffusion.model, self.flat, model.diffusion.diffusion, B, N, ctx_mode, ctx_dim, L,
                              text_dim, backend, per_block_grads=per_block, ctx_param=ctx_param,
-                             grad_scale=1.0 / (B * ws))
+                             grad_scale=1.0 / (B * ws),
+                             tn_flush_floats=self.flat.numel // 3 if (distributed and not per_block) else None)
             ent = {"plan": plan, "graph": None, "reducer": None, "warm": 0}
             if distributed:
                 from .ddp import FlatGradientReducer

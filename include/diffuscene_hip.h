@@ -77,7 +77,13 @@ typedef struct dsc_gemm_args {
      * When set (and n % 128 == 0, 16-byte aligned y / bias / residual), dsc_gemm_f32 and dsc_gemm_gn_silu_f32 compute
      * the SAME f32 product on the bf16 matrix cores: both operands split exactly into 3 bf16 pieces, the 6 significant piece
      * products accumulated in f32 (error vs f64 <= the exact-f32 MFMA path's, ~1.5x faster).  NULL, an unsupported shape, or
-     * DSC_GEMM=f32 in the environment: the exact-f32 MFMA kernel runs. */
+     * dsc_get_gemm_arithmetic() == 0: the exact-f32 MFMA kernel runs.
+     * Operand range of the split arithmetic (tests/test_gpu_split.py holds these): finite operands with |x| <= 3.3895e38 (the largest
+     * bf16) give the f32 product at any magnitude and any mix of magnitudes inside a K row; pieces below the bf16 subnormal range
+     * (third pieces of |x| < ~1e-33) may be flushed by the matrix cores: an absolute error <= 2^-16 |x w| on such terms, invisible
+     * next to any normal-range term.  An operand that is +-inf, NaN or above the largest bf16 makes its first piece inf and its
+     * residual pieces NaN, and a product that overflows f32 may meet an oppositely signed piece product: the affected outputs are
+     * non-finite in both arithmetics, but NaN where the exact-f32 kernel may give +-inf. */
     const uint16_t* w_planes;
 } dsc_gemm_args;
 
@@ -89,6 +95,15 @@ int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
 /* Which arithmetic dsc_gemm_f32 (gn = 0) / dsc_gemm_gn_silu_f32 (gn != 0) would use for this launch: 1 = the split-bf16 kernel (planes
  * supplied, shape / alignment covered, launch large enough to fill the chip, DSC_GEMM != f32), 0 = the exact-f32 MFMA kernel. */
 int dsc_gemm_arithmetic(const dsc_gemm_args* args, int32_t gn);
+
+/* The arithmetic switch of dsc_gemm_f32 / dsc_gemm_gn_silu_f32 / the grouped weight-gradient launch chosen by the host code -- the ONE
+ * source of truth (the Python engine, the training plan and bench.py ask this function, nothing else parses the environment):
+ *   1 = split-bf16 wherever a launch qualifies (default), 0 = exact-f32 MFMA everywhere.
+ * Initial value from the environment, strictly: DSC_GEMM unset, "" or "split" -> 1; "f32" -> 0; any other value -> get returns
+ * DSC_EINVAL and every GEMM launch fails with DSC_EINVAL.  set(mode) switches it per call, process-wide (0 / 1, else DSC_EINVAL);
+ * launches already captured in a hipGraph keep the kernels they were captured with. */
+int dsc_get_gemm_arithmetic(void);
+int dsc_set_gemm_arithmetic(int32_t mode);
 
 typedef struct dsc_split_item { const float* w; int64_t ldw; int32_t rows, cols; uint16_t* planes; int32_t transpose; } dsc_split_item;
 int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream);
@@ -259,10 +274,11 @@ int dsc_gn_silu_bwd_f32(const float* z, int64_t ldz, const float* dy, int64_t ld
 typedef struct dsc_ws_bwd_item { const float* w; const float* dw_std; float* dw; int32_t rows; int32_t cols; } dsc_ws_bwd_item;
 int dsc_weight_standardize_bwd_f32(const dsc_ws_bwd_item* items, int32_t count, float eps, dsc_stream_t stream);
 
-/* Backward of dsc_layernorm_f32: dx, and per-block partials of the gain gradient [partial_rows][512]. */
+/* Backward of dsc_layernorm_f32: dx (+ addend when not NULL: the gradient x already holds from another consumer -- dx may be a
+ * different buffer than addend, so nothing is modified in place), and per-block partials of the gain gradient [partial_rows][512]. */
 int dsc_layernorm_bwd_f32(const float* x, int64_t ldx, const float* g, const float* dy, int64_t ldy, float* dx,
-                          int64_t lddx, float* dg_partial, int32_t partial_rows, int32_t m, int32_t d, float eps,
-                          dsc_stream_t stream);
+                          int64_t lddx, const float* addend, int64_t ldadd, float* dg_partial, int32_t partial_rows, int32_t m,
+                          int32_t d, float eps, dsc_stream_t stream);
 
 int dsc_linear_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                  const float* dout, int64_t ldo, float* dq, int64_t lddq, float* dk, int64_t lddk,

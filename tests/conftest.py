@@ -34,3 +34,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def gemm_arith(request):
+    """Run a test under a given GEMM arithmetic ('split' | 'f32') IN THIS PROCESS: the library's per-call switch
+    (dsc_set_gemm_arithmetic), restored afterwards.  Use with
+    ``@pytest.mark.parametrize("gemm_arith", ["split", "f32"], indirect=True)`` -- one pytest session then holds the goldens under both."""
+    from diffuscene_amd import _lib
+    prev = _lib.set_gemm_arithmetic(request.param)
+    yield request.param
+    _lib.set_gemm_arithmetic(prev)

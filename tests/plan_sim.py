@@ -311,7 +311,7 @@ class SimBackend:
                 o.view(o.shape[0], -1).copy_(gw.float())
         return self._step("ws_bwd", f)
 
-    def layernorm_bwd(self, x, g, dy, dx, dg_part):
+    def layernorm_bwd(self, x, g, dy, dx, dg_part, addend=None):
         def f():
             with torch.enable_grad():
                 xd = x.double().clone().requires_grad_(True)
@@ -320,7 +320,7 @@ class SimBackend:
                 var = xd.var(dim=1, unbiased=False, keepdim=True)
                 y = (xd - mean) * (var + EPS).rsqrt() * gd
                 gx, gg = torch.autograd.grad(y, [xd, gd], dy.double())
-            dx.copy_(gx.float())
+            dx.copy_((gx if addend is None else gx + addend.double()).float())
             dg_part.zero_()
             dg_part[0].copy_(gg.float())
         return self._step("layernorm_bwd", f)

@@ -37,7 +37,8 @@ def _model(tmp_path):
     return net, diff
 
 
-def test_training_step_at_b256_plan_and_graph(golden_dir, tmp_path):
+@pytest.mark.parametrize("gemm_arith", ["split", "f32"], indirect=True)
+def test_training_step_at_b256_plan_and_graph(golden_dir, tmp_path, gemm_arith):
     from diffuscene_amd._lib import SS_PER_SLOT
     from diffuscene_amd.flat import FlatStorage
     from diffuscene_amd.train_plan import HipBackend, TrainPlan
@@ -83,7 +84,8 @@ def test_training_step_at_b256_plan_and_graph(golden_dir, tmp_path):
     assert bool(same.all()), "graph replay must reproduce the eager launches bit for bit"
 
 
-def test_reverse_step_at_b256(golden_dir, tmp_path):
+@pytest.mark.parametrize("gemm_arith", ["split", "f32"], indirect=True)
+def test_reverse_step_at_b256(golden_dir, tmp_path, gemm_arith):
     from diffuscene_amd.sampler import NoiseReplay
     g = np.load(os.path.join(golden_dir, "b256.npz"))
     kw, x, t, cond, noise, step_noise = b256_inputs()

@@ -43,8 +43,9 @@ def _model(name, tmp_path, time_num=1000):
     return net, diff
 
 
+@pytest.mark.parametrize("gemm_arith", ["split", "f32"], indirect=True)
 @pytest.mark.parametrize("name", ["bedroom21", "text", "arrange"])
-def test_training_step_at_full_batch(name, golden_dir, tmp_path):
+def test_training_step_at_full_batch(name, golden_dir, tmp_path, gemm_arith):
     from diffuscene_amd._lib import SS_PER_SLOT, SS_PER_TOKEN
     from diffuscene_amd.flat import FlatStorage
     from diffuscene_amd.train_plan import HipBackend, TrainPlan
@@ -120,7 +121,8 @@ def test_reverse_step_at_full_batch(name, golden_dir, tmp_path):
     assert abs(s - want_s) <= 1e-5 * want_a, (s, want_s)
 
 
-def test_completion_loop_at_b128(golden_dir, tmp_path):
+@pytest.mark.parametrize("gemm_arith", ["split", "f32"], indirect=True)
+def test_completion_loop_at_b128(golden_dir, tmp_path, gemm_arith):
     from diffuscene_amd.sampler import NoiseReplay
     g = np.load(os.path.join(golden_dir, "fullbatch.npz"))
     kw, x, t, cond, _, _, _ = fullbatch_inputs("complete")

@@ -188,7 +188,8 @@ def test_two_chain_graph_equals_eager_large_batch(monkeypatch):
     with torch.no_grad():
         eager = diff.gen_samples((B, N, C), dev(), condition=cond, noise_fn=_replay(seq), graph=False)
         graph = diff.gen_samples((B, N, C), dev(), condition=cond, noise_fn=_replay(seq), graph=True)
-    if os.environ.get("DSC_GEMM", "split") == "f32":
+    from diffuscene_amd import _lib
+    if not _lib.split_enabled():
         assert torch.equal(eager, graph)
     assert rel(graph, eager) < 1e-5
 

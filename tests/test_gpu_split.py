@@ -9,7 +9,12 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-SPLIT_ON = os.environ.get("DSC_GEMM", "split") != "f32"      # DSC_GEMM=f32: every launch stays on the exact-f32 MFMA kernel
+
+
+def split_on():
+    """The library's arithmetic switch (DSC_GEMM=f32 / set_gemm_arithmetic("f32"): every launch stays on the exact-f32 MFMA kernel)."""
+    from diffuscene_amd import _lib
+    return _lib.split_enabled()
 
 
 def dev():
@@ -70,8 +75,8 @@ def test_split_gemm_plain(m, n, k, taken):
     # same rounding-noise class as the exact-f32 kernel, whose own rms moves by 30 % with its tile's summation order (measured:
     # 0.8 .. 1.4 x the f32 kernel's at K >= 128; 2 x at K = 96 where both are ~1e-7)
     assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
-    assert torch.equal(y, y32) != (taken and SPLIT_ON), "dispatch: split path %s this launch" % ("did not take" if taken else "took")
-    assert ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd, w_planes=pl)) == (taken and SPLIT_ON)      # the library's own answer
+    assert torch.equal(y, y32) != (taken and split_on()), "dispatch: split path %s this launch" % ("did not take" if taken else "took")
+    assert ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd, w_planes=pl)) == (taken and split_on())      # the library's own answer
     assert not ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd))
 
 
@@ -139,7 +144,7 @@ def test_split_gemm_groupnorm_block(B, N, mode):
     z, ref = _gn_ref(a, w, b, gamma, beta, N, ss, mode, res, idx)
     assert rel(pre, z) < 2e-6 and rel(y, ref) < 5e-6, (rel(pre, z), rel(y, ref))
     assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
-    assert torch.equal(pre, pre32) != SPLIT_ON, "dispatch: the split path must take this launch (and only without DSC_GEMM=f32)"
+    assert torch.equal(pre, pre32) != split_on(), "dispatch: the split path must take this launch (and only without DSC_GEMM=f32)"
 
 
 def test_split_path_falls_back_where_it_does_not_apply():
@@ -159,3 +164,108 @@ def test_split_path_falls_back_where_it_does_not_apply():
         w5, b5, g5, be5 = rnd(512, 512, seed=6, scale=0.1).to(d), rnd(512, seed=7).to(d), (rnd(512, seed=8) + 1.5).to(d), rnd(512, seed=9).to(d)
         (p5,) = ops.split_planes([(w5, None, False)])
         assert torch.equal(ops.gemm_gn_silu(x, w5, b5, g5, be5, N, w_planes=p5), ops.gemm_gn_silu(x, w5, b5, g5, be5, N))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# operand range of the split arithmetic (the contract written in include/diffuscene_hip.h next to dsc_gemm_args.w_planes)
+# ---------------------------------------------------------------------------------------------------------------------
+def _both(a, w, b=None):
+    """(split result, exact-f32 result, launch was taken by the split kernel)."""
+    from diffuscene_amd import ops
+    ad, wd = a.to(dev()), w.to(dev())
+    bd = b.to(dev()) if b is not None else None
+    (pl,) = ops.split_planes([(wd, None, False)])
+    y = ops.gemm(ad, wd, bd, w_planes=pl)
+    y32 = ops.gemm(ad, wd, bd)
+    return y, y32, ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd, w_planes=pl))
+
+
+@pytest.mark.parametrize("sa,sw", [(1e-15, 1e-15), (1e15, 1e15), (1e30, 1e-30), (1e-30, 1e30), (1e-18, 1e18), (3e18, 3e18), (1e-19, 1e-19)])
+def test_split_product_is_scale_free(sa, sw):
+    """bf16 pieces keep the f32 exponent: the six-product sum is as accurate at 1e-30 / 1e+30 operand magnitudes as at 1 (products
+    from 1e-38 to 1e+37), measured against f64 and against the exact-f32 kernel on the same operands."""
+    m, n, k = 20480, 512, 512
+    a, w = rnd(m, k, seed=21) * sa, rnd(n, k, seed=22) * sw
+    y, y32, taken = _both(a, w)
+    assert taken == split_on()
+    ref = a.double() @ w.double().T
+    assert bool(torch.isfinite(y).all())
+    assert rel(y, ref) < 2e-6, rel(y, ref)
+    assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (rms_err(y, ref), rms_err(y32, ref))
+
+
+def test_split_product_mixed_magnitudes_inside_a_k_row():
+    """Columns of A and W scaled by 10^U(-6,6) with opposite exponents (every product is O(1), every OPERAND row spans 12 decades) and,
+    second case, uncorrelated exponents (a few products dominate each sum): error vs f64 in the f32 kernel's class either way."""
+    m, n, k = 20480, 512, 512
+    g = torch.Generator().manual_seed(5)
+    e = (torch.rand(k, generator=g) * 12 - 6)
+    for mirrored in (True, False):
+        ew = -e if mirrored else (torch.rand(k, generator=g) * 12 - 6)
+        a, w = rnd(m, k, seed=23) * (10.0 ** e)[None, :], rnd(n, k, seed=24) * (10.0 ** ew)[None, :]
+        y, y32, taken = _both(a, w)
+        assert taken == split_on()
+        ref = a.double() @ w.double().T
+        assert rel(y, ref) < 2e-6, (mirrored, rel(y, ref))
+        assert rms_err(y, ref) <= max(1.5 * rms_err(y32, ref), 2.5e-7), (mirrored, rms_err(y, ref), rms_err(y32, ref))
+
+
+def test_split_product_large_finite_and_subnormal_operands():
+    """Up to the largest bf16 (3.3895e38) an operand splits finitely: rows holding +-3.3e38 against weights of 1e-3 give the f32
+    product.  Subnormal operands (|x| < 1.18e-38) and third pieces below the bf16 subnormal range may be flushed by the matrix cores:
+    the absolute error they can cause is bounded by 2^-16 of the flushed terms, far below one ulp of any normal-range result."""
+    m, n, k = 20480, 512, 512
+    a, w = rnd(m, k, seed=25), rnd(n, k, seed=26) * 1e-3
+    a[::7, ::5] = 3.3e38
+    a[3::7, 1::5] = -3.3e38
+    y, y32, taken = _both(a, w)
+    assert taken == split_on()
+    ref = a.double() @ w.double().T
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(y32).all())
+    assert rel(y, ref) < 2e-6
+    # subnormal and near-subnormal operands next to normal ones: result = normal part +- negligible
+    a2, w2 = rnd(m, k, seed=27), rnd(n, k, seed=28)
+    a2[:, ::3] *= 1e-40                               # subnormal f32
+    a2[:, 1::3] *= 1e-35                              # normal, third piece below 1e-40
+    y, y32, _ = _both(a2, w2)
+    ref = a2.double() @ w2.double().T
+    assert rel(y, ref) < 2e-6 and rel(y32, ref) < 2e-6
+    # an all-tiny problem: operands 1e-25 -> products 1e-50 underflow to zero in BOTH arithmetics (f32 range, not a split property)
+    y, y32, _ = _both(rnd(m, k, seed=29) * 1e-25, rnd(n, k, seed=30) * 1e-25)
+    assert float(y.abs().max()) == 0.0 and float(y32.abs().max()) == 0.0
+
+
+def test_split_product_non_finite_operands_stay_non_finite_where_f32_is():
+    """+-inf / NaN operands and operands above the largest bf16: the outputs they reach are non-finite in BOTH arithmetics (the split
+    kernel gives NaN where the exact-f32 kernel may give +-inf: inf - bf16(inf) = NaN in the residual pieces -- documented in
+    include/diffuscene_hip.h), every other output is untouched; products that overflow f32 are non-finite in both."""
+    m, n, k = 20480, 512, 512
+    a, w = rnd(m, k, seed=31), rnd(n, k, seed=32)
+    a[5, 17] = float("inf")
+    a[6, 18] = float("-inf")
+    a[7, 19] = float("nan")
+    a[8, 20] = 3.4e38                                 # finite f32 above the largest bf16: first piece rounds to inf
+    w[9, 21] = float("inf")
+    w[10, 22] = float("nan")
+    y, y32, taken = _both(a, w)
+    assert taken == split_on()
+    bad_rows = torch.zeros(m, dtype=torch.bool)
+    bad_rows[[5, 6, 7]] = True
+    bad_cols = torch.zeros(n, dtype=torch.bool)
+    bad_cols[[9, 10]] = True
+    want_bad = bad_rows[:, None] | bad_cols[None, :]
+    nf, nf32 = ~torch.isfinite(y).cpu(), ~torch.isfinite(y32).cpu()
+    assert torch.equal(nf32, want_bad)                                        # the exact-f32 kernel: exactly the reached outputs
+    if split_on():
+        want_split = want_bad.clone()
+        want_split[8, :] = True                                               # 3.4e38 > bf16 max: documented NaN row
+        assert torch.equal(nf, want_split)
+    ok = ~(want_bad | (torch.arange(m) == 8)[:, None])
+    ref = a.double() @ w.double().T
+    assert float(((y.double().cpu() - ref)[ok]).abs().max() / ref[ok].abs().max()) < 2e-6
+    # overflow of the PRODUCT (1e30 * 1e30): non-finite in both
+    a3, w3 = rnd(512, k, seed=33) * 1e30, rnd(n, k, seed=34) * 1e30
+    a3 = a3.repeat(40, 1)
+    y, y32, _ = _both(a3, w3)
+    assert not bool(torch.isfinite(y).any()) or not split_on()
+    assert float(torch.isfinite(y32).float().mean()) < 0.01

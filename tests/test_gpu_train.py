@@ -396,14 +396,14 @@ def test_fused_adam_matches_torch_adam_with_clipping():
         cpu.step()
 
 
-@pytest.mark.parametrize("arith", ["split", "f32"])
+@pytest.mark.parametrize("gemm_arith", ["split", "f32"], indirect=True)
 @pytest.mark.parametrize("scale", [1, 40])
-def test_grouped_weight_gradient_gemm(scale, arith, monkeypatch):
+def test_grouped_weight_gradient_gemm(scale, gemm_arith):
     """dsc_gemm_tn_grouped_[split_]f32: many weight gradients in one launch (mixed shapes: two K segments, zero-padded small K with
     kvalid, bias column sums, tiny token counts, a ragged token tail) vs fp64; `scale` makes the group large enough for the unsplit
-    path; both arithmetics: the split-bf16 form (default) and the exact-f32 MFMA kernel (DSC_GEMM=f32)."""
+    path; both arithmetics: the split-bf16 form (default) and the exact-f32 MFMA kernel (set_gemm_arithmetic("f32"))."""
     from diffuscene_amd.train_plan import HipBackend
-    monkeypatch.setenv("DSC_GEMM", arith)
+    arith = gemm_arith
     be = HipBackend(dev())
     assert be.split == (arith == "split")
     M = 1290

@@ -11,6 +11,7 @@ import os
 import subprocess
 import sys
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -96,3 +97,43 @@ def test_dispatch_decision_of_the_library():
     #        dense  GN80   GN80/B128  GN21   small  GN12  no planes  n%128  unaligned y  N=96  grouped  two segments
     assert _decide() == [1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1]
     assert _decide({"DSC_GEMM": "f32"}) == [0] * 12
+
+
+def test_arithmetic_switch_is_one_source_of_truth():
+    """DSC_GEMM was parsed in three places with different rules.  Now the library owns the switch
+    (dsc_get / dsc_set_gemm_arithmetic): the environment is read once, strictly ('split' | 'f32'), unknown values are REJECTED at load,
+    and the per-call switch moves the library's dispatch and the host code's view (engine, training plan, bench) together."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from diffuscene_amd import _lib
+print("OK", _lib.split_enabled())
+''' % ROOT
+    for val, want in ((None, "OK True"), ("split", "OK True"), ("f32", "OK False")):
+        e = dict(os.environ)
+        e.pop("DSC_GEMM", None)
+        if val is not None:
+            e["DSC_GEMM"] = val
+        assert subprocess.check_output([sys.executable, "-c", code], env=e, text=True).strip().splitlines()[-1] == want
+    for bad in ("fp32", "float", "F32", "bf16"):
+        e = dict(os.environ, DSC_GEMM=bad)
+        r = subprocess.run([sys.executable, "-c", code], env=e, text=True, capture_output=True)
+        assert r.returncode != 0 and "must be 'split' (default) or 'f32'" in r.stderr, (bad, r.stderr[-300:])
+    # per-call switch, in this process
+    from diffuscene_amd import _lib
+    lib = _lib.load()
+    start = "split" if _lib.split_enabled() else "f32"
+    try:
+        assert _lib.set_gemm_arithmetic("f32") == start and not _lib.split_enabled() and lib.dsc_get_gemm_arithmetic() == 0
+        g = _lib.GemmArgs()
+        g.a1, g.lda1, g.k1, g.w, g.ldw, g.y, g.ldy, g.m, g.n, g.batch = 0x1000000, 512, 512, 0x3000000, 512, 0x4000000, 512, 20480, 512, 1
+        g.w_planes = 0x5000000
+        import ctypes as C
+        assert lib.dsc_gemm_arithmetic(C.byref(g), 0) == 0
+        assert _lib.set_gemm_arithmetic("split") == "f32" and _lib.split_enabled()
+        assert lib.dsc_gemm_arithmetic(C.byref(g), 0) == 1
+        assert lib.dsc_set_gemm_arithmetic(7) != 0 and _lib.split_enabled()
+        with pytest.raises(ValueError):
+            _lib.set_gemm_arithmetic("fp32")
+    finally:
+        _lib.set_gemm_arithmetic(start)

@@ -40,8 +40,10 @@ def test_a_slice_is_at_least_256_tokens_of_the_bulk():
 
 def test_text_training_plan_builds_on_the_host_with_short_slice_counts(tmp_path, monkeypatch):
     """The whole training plan of BASELINE configs[3] (B=128, N=12, L=32) is BUILT on the host -- argument structs, device tables, the
-    launch list; nothing is launched, only the HIP-device check of the table-building code is bypassed -- and its three grouped
-    weight-gradient launches are cut into 2 / 6 / 3 token slices (32 each before the fix)."""
+    launch list; nothing is launched, only the HIP-device check of the table-building code is bypassed.  Round 3: its three grouped
+    weight-gradient launches were cut into 2 / 6 / 3 token slices (32 each before the slice-rule fix).  Round 4: nothing forces an
+    early flush of the pending weight-gradient GEMMs any more (out-of-place LayerNorm accumulation, column-exact hazard check), so
+    the single-GPU plan has ONE grouped launch of all 135 layers -- 1042 bulk tiles, un-sliced, no slabs, no reduction launch."""
     import contextlib
     import io
     import json
@@ -72,4 +74,5 @@ def test_text_training_plan_builds_on_the_host_with_short_slice_counts(tmp_path,
     tb = {n: getattr(d, n).float() for n in d._TABLE_NAMES}
     plan = train_plan.TrainPlan(net, flat, d, 128, 12, SS_PER_SLOT, 128, 32, 512, train_plan.HipBackend(torch.device("cpu")), tables=tb)
     assert len(plan.fwd) > 150 and len(plan.bwd) > 250
-    assert [r for _, r in chosen] == [(2, 1536), (6, 1536), (3, 1536)], chosen
+    assert chosen == [(135, (1, 1536))], chosen
+    assert plan.n_adds == 8              # only the 8 skip-connection adds are left (round 3: 8 + one per LayerNorm input)
