@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
         ("preact", C.c_void_p), ("ld_preact", C.c_int64),
         ("ss_index", C.c_void_p),
         ("w_planes", C.c_void_p),
+        ("actgrad_x", C.c_void_p), ("ld_actgrad", C.c_int64),
     ]
 
 

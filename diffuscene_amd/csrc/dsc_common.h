@@ -48,6 +48,21 @@ __device__ __forceinline__ float dsc_act(float x, int act) {
     return x;
 }
 
+// d act(x) / dx (dsc_activation_bwd_f32 and the actgrad_x epilogue of the split GEMM share it: same values either way)
+__device__ __forceinline__ float dsc_act_grad(float xv, int act) {
+    if (act == DSC_ACT_GELU) {
+        const float cdf = 0.5f * (1.0f + dsc_erf(xv * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * xv * xv);
+        return cdf + xv * pdf;
+    }
+    if (act == DSC_ACT_SILU) {
+        const float sig = 1.0f / (1.0f + expf(-xv));
+        return sig * (1.0f + xv * (1.0f - sig));
+    }
+    if (act == DSC_ACT_LEAKY01) return xv > 0.0f ? 1.0f : 0.1f;
+    return 1.0f;
+}
+
 // butterfly reductions over the 64 lanes of a wave
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

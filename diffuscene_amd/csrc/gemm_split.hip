@@ -101,9 +101,24 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch bch)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// WM x WN waves (8: one block per CU owns the LDS; 4: half the channels per block for launches that would otherwise leave CUs idle)
-template <bool GN, int WM, int WN, int RB, bool DSPREAD = DSC_SPLIT_DSPREAD>
-__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_gemm_args p, const int ntok) {
+// LDS bytes of a WM x WN x RB tile: two stages of (3 token planes + 3 weight planes) + the dump slot of a ragged item round
+template <int WM, int WN, int RB>
+constexpr int split_smem_bytes() {
+    constexpr int BM = 16 * RB * WM, BN = 64 * WN;
+    constexpr int STAGE = 3 * BM * BK * 2 + 3 * BN * BK * 2;
+    constexpr int ITEMS_W = BM * 4 / (WM * WN);
+    return 2 * STAGE + ((ITEMS_W % 64) ? 1024 : 0);
+}
+
+// One output tile of one launch: block `bid` of problem `zb` (the body of gemm_split_kernel; a device function so that a persistent
+// launch can run several tiles / layers per block -- tools/two_layer_probe.hip, the round-4 GO / NO-GO experiment).
+struct NoSync { __device__ __forceinline__ void operator()() const {} };
+
+// `sync` runs after the weight DMA of the first K tile has been issued and before the first token rows are read: a persistent launch
+// waits there for the producer of its input rows (the weights do not depend on it).
+template <bool GN, int WM, int WN, int RB, bool DSPREAD, class Sync = NoSync>
+__device__ __forceinline__ void gemm_split_tile(const dsc_gemm_args& p, const int ntok, const int bid, const int zb, char* const smem,
+                                                const Sync sync = Sync{}) {
     constexpr int NW = WM * WN, T = 64 * NW;
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
     constexpr int BM = 16 * RB * WM, BN = 64 * WN;       // BM = LDS rows (scenes padded to 16*RB); global rows = WM * ntok
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
     constexpr int DUMP = (ITEMS_W % 64) ? 1024 : 0;      // where the idle lanes of a ragged item round write
     static_assert(NIT <= RB && NIT <= 3, "the splits ride in the last NIT token blocks of a tile");
     static_assert(2 * STAGE + DUMP <= 160 * 1024, "two stages must fit the 160 KiB LDS");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + DUMP];
+    static_assert(2 * STAGE + DUMP == split_smem_bytes<WM, WN, RB>(), "split_smem_bytes");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave_u % WM, wn = wave_u / WM;
@@ -125,18 +140,18 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
     const int cbs = p.n / BN, rbs = (scenes + WM - 1) / WM;
     int rb, cb;
     if ((rbs & 7) == 0) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = bid & 7, idx = bid >> 3;
         rb = xcd * (rbs >> 3) + idx / cbs;
         cb = idx % cbs;
     } else {
-        rb = blockIdx.x / cbs;
-        cb = blockIdx.x % cbs;
+        rb = bid / cbs;
+        cb = bid % cbs;
     }
     const int row0 = rb * WM * ntok, col0 = cb * BN;     // first global token row of the block
     const int rows_here = p.m - row0;                    // valid global rows from row0 on (may exceed the block)
-    // grouped launch (batch > 1): problem z = blockIdx.y; its weights are rows [z n, (z+1) n) of ONE stacked matrix whose planes
+    // grouped launch (batch > 1): problem z = zb (zb); its weights are rows [z n, (z+1) n) of ONE stacked matrix whose planes
     // are [3][batch n][K]
-    const int z = blockIdx.y;
+    const int z = zb;
     const float* const xb1 = p.a1 + (int64_t)z * p.sa1 + (int64_t)row0 * p.lda1;
     const float* const xb2 = p.a2 ? p.a2 + (int64_t)z * p.sa2 + (int64_t)row0 * p.lda2 : xb1;
     const uint16_t* const wb = p.w_planes + ((int64_t)z * p.n + col0) * K;
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
 
     const int KT = K / BK;
     dma_tile(0, smem);
+    sync();
     load_items(0);
 #pragma unroll
     for (int u = 0; u < NIT; ++u) store_item(u, smem);
@@ -335,13 +351,21 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
     float* const ob = p.y + (int64_t)z * p.sy + (int64_t)(row0 + srow + l15) * p.ldy + cbase;
     const float* const rbp = p.residual ? p.residual + (int64_t)z * p.sres + (int64_t)(row0 + srow + l15) * p.ldr + cbase : nullptr;
     if constexpr (!GN) {
+        // training-step forms (include/diffuscene_hip.h): u also stored to `preact`; or the result multiplied by act_out'(actgrad_x)
+        float* const ub = p.preact ? p.preact + (int64_t)z * p.sy + (int64_t)(row0 + srow + l15) * p.ld_preact + cbase : nullptr;
+        const float* const gb = p.actgrad_x ? p.actgrad_x + (int64_t)z * p.sy + (int64_t)(row0 + srow + l15) * p.ld_actgrad + cbase : nullptr;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             if (valid[i]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 y = acc[i][j];
-                    if (p.act_out != DSC_ACT_NONE) {
+                    if (ub) *reinterpret_cast<f32x4*>(ub + (int64_t)i * 16 * p.ld_preact + j * 16) = y;
+                    if (gb) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(gb + (int64_t)i * 16 * p.ld_actgrad + j * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] *= dsc_act_grad(u[e], p.act_out);
+                    } else if (p.act_out != DSC_ACT_NONE) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = dsc_act(y[e], p.act_out);
                     }
@@ -434,6 +458,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_g
     }
 }
 
+// WM x WN waves (8: one block per CU owns the LDS; 4: half the channels per block for launches that would otherwise leave CUs idle)
+template <bool GN, int WM, int WN, int RB, bool DSPREAD = DSC_SPLIT_DSPREAD>
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_kernel(const dsc_gemm_args p, const int ntok) {
+    __shared__ __attribute__((aligned(16))) char smem[split_smem_bytes<WM, WN, RB>()];
+    gemm_split_tile<GN, WM, WN, RB, DSPREAD>(p, ntok, blockIdx.x, blockIdx.y, smem);
+}
+
 template <bool GN, int WM, int WN, int RB>
 int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
     constexpr int BN = 64 * WN;
@@ -483,6 +514,8 @@ static int select_tile(const dsc_gemm_args* a, bool gn) {
     if (!dsc_aligned16(a->w_planes) || !dsc_aligned16(a->y) || (a->ldy & 3)) return -1;
     if (a->bias && !dsc_aligned16(a->bias)) return -1;
     if (a->residual && (!dsc_aligned16(a->residual) || (a->ldr & 3))) return -1;
+    if (!gn && a->preact && (!dsc_aligned16(a->preact) || (a->ld_preact & 3) || a->batch != 1)) return -1;
+    if (a->actgrad_x && (gn || !dsc_aligned16(a->actgrad_x) || (a->ld_actgrad & 3) || a->batch != 1)) return -1;
     if (3LL * a->batch * a->n * K * 2 >= 0x7fffffffLL) return -1;                       // 32-bit DMA offsets into the planes
     const int64_t ld_max = a->lda1 > a->lda2 ? a->lda1 : a->lda2;
     if (ld_max * 4 * 320 >= 0x7fffffffLL) return -1;                                    // 32-bit byte offsets inside a token tile

@@ -1327,19 +1327,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < count; i += stride) {
-        const float xv = x[i];
-        float d;
-        if (act == DSC_ACT_GELU) {
-            const float cdf = 0.5f * (1.0f + dsc_erf(xv * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * expf(-0.5f * xv * xv);
-            d = cdf + xv * pdf;
-        } else if (act == DSC_ACT_SILU) {
-            const float sig = 1.0f / (1.0f + expf(-xv));
-            d = sig * (1.0f + xv * (1.0f - sig));
-        } else if (act == DSC_ACT_LEAKY01) {
-            d = xv > 0.0f ? 1.0f : 0.1f;
-        } else d = 1.0f;
-        dx[i] = dy[i] * d;
+        dx[i] = dy[i] * dsc_act_grad(x[i], act);
     }
 }
 

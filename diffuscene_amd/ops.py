@@ -41,7 +41,7 @@ def as2d(w):
 
 def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
                    gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None,
-                   ss_index=None, w_planes=None):
+                   ss_index=None, w_planes=None, actgrad_x=None):
     """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
     pointers only; the caller keeps the tensors alive.  ``w_planes``: the weight pre-split into bf16 planes (split_planes):
     the product runs on the bf16 matrix cores with f32 accuracy where the kernel supports the shape."""
@@ -74,6 +74,10 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         g.ss_mode = ss_mode
     if preact is not None:
         g.preact, g.ld_preact = _mat(preact, "preact")
+    if actgrad_x is not None:              # y = product * act_out'(actgrad_x) (split kernel only; include/diffuscene_hip.h)
+        g.actgrad_x, g.ld_actgrad = _mat(actgrad_x, "actgrad_x")
+        if tuple(actgrad_x.shape) != (g.m, g.n):
+            raise RuntimeError("actgrad_x shape %s != (%d, %d)" % (tuple(actgrad_x.shape), g.m, g.n))
     if ss_index is not None:
         g.ss_index = _dev(ss_index, "ss_index", torch.int64).data_ptr()
     if w_planes is not None:

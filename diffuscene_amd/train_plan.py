@@ -38,10 +38,12 @@ def _as2d(w):
 
 class H:
     """Activation handle: forward tensor + (build-time) gradient tensor."""
-    __slots__ = ("t", "g", "ng")
+    __slots__ = ("t", "g", "ng", "act_of", "g_pre")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.g, self.ng = t, None, needs_grad
+        self.act_of = None        # (pre-activation tensor, kind) when this handle is act(pre-activation) with ONE consumer
+        self.g_pre = None         # gradient w.r.t. the pre-activation, written directly by the consumer's input-gradient GEMM
 
 
 # ======================================================================================================================
@@ -141,9 +143,25 @@ class HipBackend:
         return holder
 
     # -- forward ops
-    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE):
+    def fuse_act_ok(self, a, w, out, a2=None):
+        """Can this product carry an activation epilogue of the training step (pre-activation also stored / result multiplied by the
+        derivative)?  Only the split-bf16 kernel implements them: ask the library whether it takes the launch."""
+        from . import ops
+        if not self.split or a.shape[0] < 256:
+            return False
+        g = ops.make_gemm_args(a, w, out, None, a2)
+        return ops.gemm_would_use_split(g) and self.planes_of(w, a.shape[0]) is not None
+
+    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE, preact=None, actgrad_x=None):
         from . import ops
         m, K = a.shape
+        if preact is not None or actgrad_x is not None:
+            g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out, preact=preact, actgrad_x=actgrad_x)
+            pl = self.planes_of(w, m)
+            if pl is None or not ops.gemm_would_use_split(g):
+                raise RuntimeError("HipBackend.gemm: an activation epilogue was planned for a launch the split kernel does not take")
+            g.w_planes = pl.data_ptr()
+            return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl, preact, actgrad_x))
         # short, deep products (time / context MLPs: m = B or N rows, K >= 1024): split K over the batch dimension
         tiles = ((m + 63) // 64) * ((out.shape[1] + 63) // 64)        # output tiles: fewer than CUs -> parallelise K instead
         if a2 is None and act_out == ACT_NONE and tiles < 256 and K >= 1024 and (m * out.shape[1]) % 4 == 0:
@@ -612,6 +630,14 @@ class TrainPlan:
         if a2 is None:
             if not a.ng:
                 return
+            if (a.act_of is not None and a.g is None and a.g_pre is None and dy.shape[1] <= 4096
+                    and hasattr(self.be, "fuse_act_ok") and self.be.fuse_act_ok(dy, wt, a.t)):
+                # a = act(u), this GEMM is its only consumer: d u = (dy . W) * act'(u) in the GEMM's epilogue -- the activation's
+                # backward launch (read u, read d a, write d u) disappears
+                u, kind = a.act_of
+                a.g_pre = self.new(*a.t.shape)
+                self.emit(self.be.gemm(dy, wt, a.g_pre, act_out=kind, actgrad_x=u))
+                return
             dst, acc = self.g_target(a)
             self._gemm_acc(dy, wt, dst, acc)
             return
@@ -696,15 +722,23 @@ class TrainPlan:
         return buf
 
     # ------------------------------------------------------------------------------------------------ layers
-    def linear(self, a, weight, bias, a2=None, residual=None, out=None, act_out=ACT_NONE, wt=None):
-        """y = [a | a2] @ W^T + b (+ residual).  ``out`` may be a column slice of a wider tensor (decoder heads)."""
+    def linear(self, a, weight, bias, a2=None, residual=None, out=None, act_out=ACT_NONE, wt=None, act=None):
+        """y = [a | a2] @ W^T + b (+ residual).  ``out`` may be a column slice of a wider tensor (decoder heads).
+        ``act``: returns act(y) instead -- ONE launch when the product runs on the split kernel (the pre-activation y is stored next
+        to act(y) by the GEMM's epilogue; its backward needs it), the GEMM followed by an activation launch otherwise."""
         w2 = _as2d(weight)
         n, K = w2.shape
         rows = a.t.shape[0]
         y = H(out if out is not None else self.new(rows, n))
-        self.emit(self.be.gemm(a.t, w2, y.t, bias, a2.t if a2 is not None else None,
-                               residual.t if residual is not None else None, act_out))
-        assert act_out == ACT_NONE, "training keeps activations as separate ops (their backward needs the pre-activation)"
+        assert act_out == ACT_NONE, "training keeps the pre-activation (its backward needs it): use act="
+        fused = (act is not None and residual is None and out is None and hasattr(self.be, "fuse_act_ok")
+                 and self.be.fuse_act_ok(a.t, w2, y.t, a2.t if a2 is not None else None))
+        if fused:
+            ya_t = self.new(rows, n)
+            self.emit(self.be.gemm(a.t, w2, ya_t, bias, a2.t if a2 is not None else None, None, act, preact=y.t))
+        else:
+            self.emit(self.be.gemm(a.t, w2, y.t, bias, a2.t if a2 is not None else None,
+                                   residual.t if residual is not None else None, act_out))
 
         def bw():
             dy = y.g
@@ -738,7 +772,10 @@ class TrainPlan:
             if residual is not None:
                 self.g_alias(residual, dy)
         self._tape.append(bw)
-        return y
+        if act is None:
+            return y
+        # the activation's backward is registered AFTER the linear's: the tape runs in reverse, d y must exist before bw() above reads it
+        return self.act(y, act, out=ya_t if fused else None)
 
     def smallk(self, x_slice, weight, bias):
         """First encoder layer on an un-aligned column slice of x_t (no input gradient)."""
@@ -757,11 +794,19 @@ class TrainPlan:
         self._tape.append(bw)
         return y
 
-    def act(self, x, kind):
-        y = H(self.new(*x.t.shape))
-        self.emit(self.be.act(x.t, y.t, kind))
+    def act(self, x, kind, out=None):
+        """y = act(x).  ``out``: the producing GEMM already wrote act(x) there, next to x (linear(..., act=kind)): no launch."""
+        y = H(out if out is not None else self.new(*x.t.shape))
+        if out is None:
+            self.emit(self.be.act(x.t, y.t, kind))
+        y.act_of = (x.t, kind)
 
         def bw():
+            if y.g_pre is not None:
+                # the consumer's input-gradient GEMM already applied act'(x) (g_gemm): its output IS d x
+                assert y.g is None, "an activation output whose derivative was fused must have exactly one consumer"
+                self.g_alias(x, y.g_pre)
+                return
             if y.g is None or not x.ng:
                 return
             dy = y.g
@@ -907,7 +952,7 @@ class TrainPlan:
     def encoder(self, seq, c0, k, acc):
         xf = self.x_t.view(self.M, -1)
         h = self.act(self.smallk(xf[:, c0:c0 + k], seq[0].weight, seq[0].bias), ACT_GELU)
-        h = self.act(self.linear(h, seq[2].weight, seq[2].bias), ACT_GELU)
+        h = self.linear(h, seq[2].weight, seq[2].bias, act=ACT_GELU)
         return self.linear(h, seq[4].weight, seq[4].bias, residual=acc)
 
     # ------------------------------------------------------------------------------------------------ build
@@ -946,8 +991,8 @@ class TrainPlan:
         eng_freq = net.time_freq.to(self.device)
         temb = H(self.new(B, D), needs_grad=False)
         self.emit(be.time_embedding(self.t, eng_table, eng_freq, temb.t))
-        t1 = self.act(self.linear(temb, net.time_mlp[1].weight, net.time_mlp[1].bias), ACT_GELU)
-        t2 = self.act(self.linear(t1, net.time_mlp[3].weight, net.time_mlp[3].bias), ACT_SILU)
+        t1 = self.linear(temb, net.time_mlp[1].weight, net.time_mlp[1].bias, act=ACT_GELU)
+        t2 = self.linear(t1, net.time_mlp[3].weight, net.time_mlp[3].bias, act=ACT_SILU)
         tw, tgw = fl.packed["t_w"]
         tbias, tgb = fl.packed["t_b"]
         ss_t = H(self.new(B, tw.shape[0]))
@@ -1081,8 +1126,8 @@ class TrainPlan:
                 heads.append((net.objfeat_hidden2output, net.objfeat_dim))
             col = 0
             for seq, width in heads:
-                d1 = self.act(self.linear(h, seq[0].weight, seq[0].bias), ACT_GELU)
-                d2 = self.act(self.linear(d1, seq[2].weight, seq[2].bias), ACT_GELU)
+                d1 = self.linear(h, seq[0].weight, seq[0].bias, act=ACT_GELU)
+                d2 = self.linear(d1, seq[2].weight, seq[2].bias, act=ACT_GELU)
                 o = self.linear(d2, seq[4].weight, seq[4].bias, out=self.out[:, col:col + width])
                 o.g = self.dout[:, col:col + width]
                 self.head_outs.append(o)

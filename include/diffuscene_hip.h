@@ -85,6 +85,14 @@ typedef struct dsc_gemm_args {
      * residual pieces NaN, and a product that overflows f32 may meet an oppositely signed piece product: the affected outputs are
      * non-finite in both arithmetics, but NaN where the exact-f32 kernel may give +-inf. */
     const uint16_t* w_planes;
+    /* ---- training-step epilogues of dsc_gemm_f32, implemented by the split-bf16 kernel only (a launch that sets them and does not
+     * qualify for that kernel -- dsc_gemm_arithmetic() == 0 -- fails with DSC_EINVAL, it is never silently ignored):
+     *   preact (above) with act_out != NONE : the pre-activation u = [A1|A2].W^T + bias is ALSO stored there, y = act_out(u)
+     *                                         (Linear + GELU / SiLU of the encoder / decoder MLPs in one launch, u kept for backward)
+     *   actgrad_x != NULL                   : y = ([A1|A2].W^T) * act_out'(actgrad_x[row][col]) (+ residual): the input-gradient GEMM
+     *                                         of the NEXT layer applies the derivative of the activation whose saved pre-activation
+     *                                         is actgrad_x (act_out names the activation; it is not applied to y) */
+    const float* actgrad_x; int64_t ld_actgrad;
 } dsc_gemm_args;
 
 int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);

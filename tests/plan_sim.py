@@ -93,17 +93,30 @@ class SimBackend:
                 s()
 
     # ---------------------------------------------------------------- forward
-    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE):
+    def fuse_act_ok(self, a, w, out, a2=None):
+        """The product backend fuses activation epilogues only into launches its split kernel takes; the dataflow of BOTH forms is
+        exercised here: fused for products with >= `fuse_rows` activation rows, separate launches below."""
+        return a.shape[0] >= getattr(self, "fuse_rows", 0)
+
+    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE, preact=None, actgrad_x=None):
         def f():
             x = torch.cat([a, a2], dim=1) if a2 is not None else a
             y = x.double() @ w.double().t()
             if bias is not None:
                 y = y + bias.double()
-            y = _act(y, act_out)
+            if preact is not None:                       # include/diffuscene_hip.h: u also stored, y = act_out(u)
+                preact.copy_(y.float())
+            if actgrad_x is not None:                    # y = product * act_out'(actgrad_x)
+                with torch.enable_grad():
+                    u = actgrad_x.double().clone().requires_grad_(True)
+                    (d,) = torch.autograd.grad(_act(u, act_out).sum(), u)
+                y = y * d
+            else:
+                y = _act(y, act_out)
             if residual is not None:
                 y = y + residual.double()
             out.copy_(y.float())
-        return self._step("gemm", f)
+        return self._step("gemm_fused_act" if (preact is not None or actgrad_x is not None) else "gemm", f)
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):
         def f():

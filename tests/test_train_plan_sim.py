@@ -66,8 +66,13 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-@pytest.mark.parametrize("case", ["uncond_slot", "text_token", "arrange_token", "uncond_slot_ddp"])
+@pytest.mark.parametrize("case", ["uncond_slot", "text_token", "arrange_token", "uncond_slot_ddp", "uncond_slot_unfused",
+                                  "uncond_slot_ddp_third"])
 def test_plan_gradients_match_autograd(case, tmp_path):
+    """Cases: conditioning modes; `_ddp` = per-block gradient flushes; `_ddp_third` = the data-parallel default (the pending
+    weight-gradient group is launched whenever it holds a third of G); `_unfused` = no activation epilogues (what the product backend
+    plans for launches its split kernel does not take: GEMM + activation launch, activation-backward launch) -- every other case fuses
+    them (pre-activation stored by the producing GEMM, act' applied by the consumer's input-gradient GEMM)."""
     from plan_sim import SimBackend
     from diffuscene_amd.flat import FlatStorage
     from diffuscene_amd.train_plan import TrainPlan
@@ -84,9 +89,23 @@ def test_plan_gradients_match_autograd(case, tmp_path):
     tb = {n: getattr(diff, n) for n in diff._TABLE_NAMES}
     slot = case.startswith("uncond_slot")
     L = 5 if text else 0
+    be = SimBackend()
+    if case.endswith("unfused"):
+        be.fuse_rows = 10 ** 9
     plan = TrainPlan(holder.net, flat, diff, B, N, SS_PER_SLOT if slot else SS_PER_TOKEN, ctx_dim, L, 512 if text else 0,
-                     SimBackend(), per_block_grads=case.endswith("ddp"),
-                     ctx_param=holder.positional_embedding if slot else None, tables=tb)
+                     be, per_block_grads=case.endswith("ddp"),
+                     ctx_param=holder.positional_embedding if slot else None, tables=tb,
+                     tn_flush_floats=flat.numel // 3 if case.endswith("ddp_third") else None)
+    if case.endswith("unfused"):
+        assert "gemm_fused_act" not in be.counts and be.counts["act"] == 15 and be.counts["act_bwd"] >= 14
+    elif arrange:                                       # no per-attribute encoder / decoder MLPs: only the time MLP's activations
+        assert be.counts["gemm_fused_act"] >= 3
+    else:
+        assert be.counts["gemm_fused_act"] >= 20 and be.counts["act"] == 4
+    if case.endswith("ddp_third"):
+        assert be.counts["gemm_tn_grouped"] == 3
+    elif not case.endswith("ddp"):
+        assert be.counts["gemm_tn_grouped"] == 1, "single GPU: ONE grouped weight-gradient launch at the end of the backward"
     C = kw["channels"]
     if arrange:
         x0 = torch.rand(B, N, C) * 2 - 1
@@ -132,6 +151,9 @@ def test_plan_gradients_match_autograd(case, tmp_path):
     if case.endswith("ddp"):
         idx = [i for i in sched if i is not None]
         assert len(set(idx)) >= 4, "per-block gradients should finish buckets at different points of the backward"
+    if case.endswith("ddp_third"):
+        idx = [i for i in sched if i is not None]
+        assert len(set(idx)) >= 3, "three grouped launches must finish buckets at three points of the backward"
 
 
 def test_plan_at_the_full_text_batch_matches_the_reference_golden(tmp_path, golden_dir):
