@@ -48,16 +48,26 @@ __device__ __forceinline__ float dsc_act(float x, int act) {
     return x;
 }
 
-// d act(x) / dx (dsc_activation_bwd_f32 and the actgrad_x epilogue of the split GEMM share it: same values either way)
+// d act(x) / dx (dsc_activation_bwd_f32 and the actgrad_x epilogue of the split GEMM share it: same values either way).  In a GEMM
+// epilogue this arithmetic is EXPOSED (every wave does it at the same moment, after the K loop), so it is kept short: GELU' = Phi(x) +
+// x phi(x) takes its Gaussian density from the exponential the erf approximation computes anyway (exp(-(x/sqrt2)^2) = exp(-x^2/2)) --
+// one v_rcp, one v_exp, ~14 FMAs; SiLU' uses the hardware reciprocal.  (Round-4 first form: libm expf twice + a division, ~45 VALU
+// per element: the fused launches lost to the epilogue what the removed activation-backward launches had saved.)
 __device__ __forceinline__ float dsc_act_grad(float xv, int act) {
     if (act == DSC_ACT_GELU) {
-        const float cdf = 0.5f * (1.0f + dsc_erf(xv * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * expf(-0.5f * xv * xv);
-        return cdf + xv * pdf;
+        const float a = fabsf(xv) * 0.70710678118654752440f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+        float p = fmaf(1.061405429f, t, -1.453152027f);
+        p = fmaf(p, t, 1.421413741f);
+        p = fmaf(p, t, -0.284496736f);
+        p = fmaf(p, t, 0.254829592f);
+        const float e = __expf(-a * a);
+        const float cdf = 0.5f * (1.0f + copysignf(1.0f - p * t * e, xv));
+        return fmaf(xv * 0.39894228040143267794f, e, cdf);
     }
     if (act == DSC_ACT_SILU) {
-        const float sig = 1.0f / (1.0f + expf(-xv));
-        return sig * (1.0f + xv * (1.0f - sig));
+        const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-xv));
+        return sig * fmaf(xv, 1.0f - sig, 1.0f);
     }
     if (act == DSC_ACT_LEAKY01) return xv > 0.0f ? 1.0f : 0.1f;
     return 1.0f;

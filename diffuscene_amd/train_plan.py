@@ -147,7 +147,7 @@ class HipBackend:
         """Can this product carry an activation epilogue of the training step (pre-activation also stored / result multiplied by the
         derivative)?  Only the split-bf16 kernel implements them: ask the library whether it takes the launch."""
         from . import ops
-        if not self.split or a.shape[0] < 256:
+        if not self.split or a.shape[0] < 256 or os.environ.get("DSC_FUSE_ACT", "1") == "0":      # (A/B switch of the measurement tools)
             return False
         g = ops.make_gemm_args(a, w, out, None, a2)
         return ops.gemm_would_use_split(g) and self.planes_of(w, a.shape[0]) is not None

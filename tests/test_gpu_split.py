@@ -180,10 +180,10 @@ def _both(a, w, b=None):
     return y, y32, ops.gemm_uses_split(ops.make_gemm_args(ad, wd, y, bd, w_planes=pl))
 
 
-@pytest.mark.parametrize("sa,sw", [(1e-15, 1e-15), (1e15, 1e15), (1e30, 1e-30), (1e-30, 1e30), (1e-18, 1e18), (3e18, 3e18), (1e-19, 1e-19)])
+@pytest.mark.parametrize("sa,sw", [(1e-15, 1e-15), (1e15, 1e15), (1e30, 1e-30), (1e-30, 1e30), (1e-18, 1e18), (1e18, 1e18), (1e-19, 1e-19)])
 def test_split_product_is_scale_free(sa, sw):
     """bf16 pieces keep the f32 exponent: the six-product sum is as accurate at 1e-30 / 1e+30 operand magnitudes as at 1 (products
-    from 1e-38 to 1e+37), measured against f64 and against the exact-f32 kernel on the same operands."""
+    from 1e-38 to 1e+36), measured against f64 and against the exact-f32 kernel on the same operands."""
     m, n, k = 20480, 512, 512
     a, w = rnd(m, k, seed=21) * sa, rnd(n, k, seed=22) * sw
     y, y32, taken = _both(a, w)
@@ -269,3 +269,72 @@ def test_split_product_non_finite_operands_stay_non_finite_where_f32_is():
     y, y32, _ = _both(a3, w3)
     assert not bool(torch.isfinite(y).any()) or not split_on()
     assert float(torch.isfinite(y32).float().mean()) < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training-step epilogues of the plain split GEMM (round 4): pre-activation stored next to act(u); result multiplied by act'(x)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("m,n,k", [(20480, 1024, 512), (5376, 512, 1024), (10240, 512, 512)])
+def test_split_gemm_training_epilogues(m, n, k, act):
+    """(a) Linear + GELU / SiLU in one launch, the pre-activation kept for the backward: u bit-identical to the plain product, y
+    bit-identical to dsc_activation_f32(u); (b) the input-gradient GEMM applying the derivative of the consumer's activation,
+    y = (dY . W) * act'(x) + residual: bit-identical to the product followed by dsc_activation_bwd_f32 and the residual add is exact
+    in the same order; both against f64.  With the exact-f32 arithmetic selected these launches are REJECTED (DSC_EINVAL), never run
+    without their epilogue."""
+    from diffuscene_amd import _lib, ops
+    d = dev()
+    a, w, b = rnd(m, k, seed=41).to(d), rnd(n, k, seed=42, scale=0.08).to(d), rnd(n, seed=43).to(d)
+    (pl,) = ops.split_planes([(w, None, False)])
+    u_ref = ops.gemm(a, w, b, w_planes=pl)
+    y, u = torch.empty(m, n, device=d), torch.empty(m, n, device=d)
+    g = ops.make_gemm_args(a, w, y, b, act_out=act, preact=u, w_planes=pl)
+    assert ops.gemm_uses_split(g) == split_on()
+    if not split_on():
+        with pytest.raises(RuntimeError):
+            ops.run_gemm(g)
+        return
+    ops.run_gemm(g)
+    assert torch.equal(u, u_ref)
+    assert torch.equal(y, ops.activation(u_ref, act))
+    z = a.double() @ w.double().T + b.double()
+    fz = F.gelu(z) if act == 1 else F.silu(z)
+    assert rel(u, z) < 2e-6 and rel(y, fz) < 2e-6
+    # (b) derivative epilogue: x = the saved pre-activation of an [m, n] activation, here u itself
+    res = rnd(m, n, seed=44).to(d)
+    prod = ops.gemm(a, w, None, w_planes=pl)
+    want = ops.activation_bwd(u, prod, act) + res
+    out = torch.empty(m, n, device=d)
+    g2 = ops.make_gemm_args(a, w, out, None, residual=res, act_out=act, actgrad_x=u, w_planes=pl)
+    ops.run_gemm(g2)
+    assert torch.equal(out, want)
+    zd = z.clone().requires_grad_(True)
+    (F.gelu(zd) if act == 1 else F.silu(zd)).sum().backward()
+    ref = (a.double() @ w.double().T) * zd.grad + res.double()
+    assert rel(out, ref) < 3e-6, rel(out, ref)
+    # accumulate in place (residual == y), as the plan's multi-consumer gradients do
+    out2 = res.clone()
+    ops.run_gemm(ops.make_gemm_args(a, w, out2, None, residual=out2, act_out=act, actgrad_x=u, w_planes=pl))
+    assert torch.equal(out2, want)
+
+
+def test_training_epilogues_are_rejected_on_the_exact_f32_kernel():
+    """A launch that asks for an activation epilogue and does not qualify for the split kernel (no planes / too few rows / exact-f32
+    arithmetic selected) fails with DSC_EINVAL."""
+    from diffuscene_amd import _lib, ops
+    d = dev()
+    a, w = rnd(300, 512, seed=45).to(d), rnd(512, 512, seed=46, scale=0.1).to(d)
+    (pl,) = ops.split_planes([(w, None, False)])
+    y, u = torch.empty(300, 512, device=d), torch.empty(300, 512, device=d)
+    with pytest.raises(RuntimeError):
+        ops.run_gemm(ops.make_gemm_args(a, w, y, None, act_out=1, preact=u, w_planes=pl))          # 300 rows: too few blocks
+    with pytest.raises(RuntimeError):
+        ops.run_gemm(ops.make_gemm_args(a, w, y, None, act_out=1, actgrad_x=u))                    # no planes
+    prev = _lib.set_gemm_arithmetic("f32")
+    try:
+        big = rnd(20480, 512, seed=47).to(d)
+        yb, ub = torch.empty(20480, 512, device=d), torch.empty(20480, 512, device=d)
+        with pytest.raises(RuntimeError):
+            ops.run_gemm(ops.make_gemm_args(big, w, yb, None, act_out=2, preact=ub, w_planes=pl))
+    finally:
+        _lib.set_gemm_arithmetic(prev)

@@ -43,6 +43,17 @@ def cpu_rng(monkeypatch):
         return out if d is None else out.to(d)
     monkeypatch.setattr(torch, "randn", randn)
     monkeypatch.setattr(torch, "randint", randint)
+    # the reverse loops take ``noise_fn=torch.randn`` as a DEFAULT ARGUMENT (bound when the function was defined, as in the reference):
+    # hand them the CPU-generator form whenever the caller left the default
+    from diffuscene_amd.networks import diffusion_ddpm as dd
+    for name in ("p_sample_loop", "p_sample_loop_trajectory", "p_sample_loop_complete", "p_sample_loop_arrange"):
+        orig = getattr(dd.GaussianDiffusion, name)
+
+        def wrapped(self, *a, _orig=orig, **kw):
+            if kw.get("noise_fn", real_randn) is real_randn:
+                kw["noise_fn"] = randn
+            return _orig(self, *a, **kw)
+        monkeypatch.setattr(dd.GaussianDiffusion, name, wrapped)
     monkeypatch.delenv("DSC_GRAPH", raising=False)            # the captured loop draws with the device generator
 
 
