@@ -593,7 +593,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("DSC_BENCH_DRYRUN"):          # launcher plumbing only (CPU test): what each rank would run
         print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "world": ws, "gpus": args.gpus,
-                          "config": args.config, "scaling": args.scaling, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+                          "config": args.config, "scaling": args.scaling, "master": os.environ.get("MASTER_ADDR"),
+                          "ddp_flush": os.environ.get("DSC_DDP_FLUSH", "end"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                          "batch_per_rank": (CONFIGS[args.config]["batch"] // ws) if args.scaling == "strong"
+                          else CONFIGS[args.config]["batch"]}), flush=True)
         if ws != args.gpus:
             raise SystemExit(2)
         return

@@ -325,3 +325,92 @@ def test_failed_capture_is_not_retried_every_step(tmp_path, monkeypatch):
         assert max(losses) - min(losses) < 1e-6 * abs(losses[0])          # same seed, same (eager) launches
     finally:
         undo()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world_size 4, UNEQUAL last shard (7 scenes -> 2 / 2 / 2 / 1), the data-parallel default schedule of round 4 (the pending weight-
+# gradient group is launched whenever it holds a third of G -> 3 grouped launches, segments cut at the bucket launches): every rank
+# builds the plan of ITS batch size; the bucket -> launch schedule, the order of the collectives and the reduced gradients must
+# agree on all ranks, and the result must be the sum of the ranks' local gradients (each scaled 1 / (B_rank * world), i.e. the mean
+# over ranks of the per-rank batch means -- what torch DDP computes for a ragged last batch as well).
+# ---------------------------------------------------------------------------------------------------------------------
+_SHARDS4 = [(0, 2), (2, 4), (4, 6), (6, 7)]
+
+
+def _plan_setup_third(B, N, seed, tmp, grad_scale):
+    holder, flat, _ = _plan_setup(B, N, seed, tmp, grad_scale, per_block=False)
+    from plan_sim import SimBackend
+    from diffuscene_amd.train_plan import TrainPlan
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.networks.diffusion_ddpm import GaussianDiffusion  # noqa: F401
+    net = holder.net
+    import contextlib
+    import io
+    import json
+    from oracle import weights as W
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    stats = os.path.join(tmp, "stats3_%d.txt" % os.getpid())
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        dp = DiffusionPoint(net, dict(objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32), time_num=1000,
+                            model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=stats)
+    tb = {n: getattr(dp.diffusion, n) for n in dp.diffusion._TABLE_NAMES}
+
+    def make_plan():
+        return TrainPlan(net, flat, dp.diffusion, B, N, SS_PER_SLOT, 128, 0, 0, SimBackend(), ctx_param=holder.positional_embedding,
+                         tables=tb, grad_scale=grad_scale, tn_flush_floats=flat.numel // 3)
+    return holder, flat, make_plan
+
+
+def _world4_worker(rank, ws, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=600))
+    torch.set_num_threads(2)
+    from diffuscene_amd import ddp
+    from diffuscene_amd.train_step import _capture
+    from oracle import weights as W
+    N = 5
+    lo, hi = _SHARDS4[rank]
+    Bl = hi - lo
+    holder, flat, make_plan = _plan_setup_third(Bl, N, seed=rank, tmp=tmp, grad_scale=1.0 / (Bl * ws))
+    ddp.broadcast_parameters(holder)
+    plan = make_plan()
+    x0 = W.synth_scene_batch(7, N, 22, 32, seed=11)
+    noise = W.synth_noise((7, N, 62), 12)
+    t = torch.tensor([5, 300, 650, 999, 17, 480, 731])
+    plan.x0.copy_(x0[lo:hi]); plan.noise.copy_(noise[lo:hi]); plan.t.copy_(t[lo:hi])
+    # local gradient of this rank's shard (no exchange)
+    plan.run_forward()
+    plan.run_backward()
+    g_local = flat.G.clone()
+    red = ddp.FlatGradientReducer(flat, plan, n_buckets=8)
+    sched = sorted((k, tuple(v)) for k, v in red.at_launch.items())
+    sg = _capture(plan, red, torch.device("cpu"))
+    for p in flat.params:                      # every gradient must be WRITTEN by the plan (alignment gaps of G stay 0)
+        flat.grad_view(p).fill_(float("nan"))
+    sg.replay()
+    assert red.finish() == len(red.buckets) >= 8
+    torch.save({"G": flat.G.clone(), "g_local": g_local, "order": list(red.last_order), "sched": sched, "segments": sg.segments,
+                "n_bwd": len(plan.bwd), "tn_launches": plan.be.counts.get("gemm_tn_grouped", 0), "B": Bl,
+                "before_last": red.launched_during_backward}, os.path.join(tmp, "w4_r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_world4_unequal_last_shard_schedule_and_gradients(tmp_path):
+    tmp = str(tmp_path)
+    mp.spawn(_world4_worker, args=(4, _free_port(), tmp), nprocs=4, join=True)
+    r = [torch.load(os.path.join(tmp, "w4_r%d.pt" % k)) for k in range(4)]
+    assert [x["B"] for x in r] == [2, 2, 2, 1]
+    # one launch list structure and one bucket schedule on every rank, whatever its batch size: the collectives match by construction
+    assert len({x["n_bwd"] for x in r}) == 1 and len({tuple(x["sched"]) for x in r}) == 1 and len({tuple(x["order"]) for x in r}) == 1
+    assert all(x["tn_launches"] == 3 for x in r), [x["tn_launches"] for x in r]
+    assert all(len(x["segments"]) >= 3 for x in r) and all(x["before_last"] >= 4 for x in r)       # buckets leave before the last segment
+    for k in range(1, 4):
+        assert torch.equal(r[0]["G"], r[k]["G"]), "every rank must hold the same reduced gradients"
+    want = sum(x["g_local"].double() for x in r)
+    got = r[0]["G"].double()
+    assert torch.isfinite(got).all()
+    assert float((got - want).norm() / want.norm()) < 1e-6
