@@ -106,3 +106,76 @@ def load_reference_package():
     for mod in ("loss", "denoise_net", "diffusion_ddpm", "diffusion_scene_layout_ddpm", "foldingnet_autoencoder"):
         out[mod] = _load_file("%s.networks.%s" % (_PARENT, mod), os.path.join(_NET_DIR, mod + ".py"))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# executing the reference's SCRIPTS (scripts/train_diffusion.py ...) in the build container
+# ---------------------------------------------------------------------------------------------------------------------
+class _AnyMeta(type):
+    def __getattr__(cls, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any
+
+
+class _Any(metaclass=_AnyMeta):
+    """Stand-in for anything a missing third-party module exports at import time (class, function, table)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any()
+
+    def __call__(self, *a, **k):
+        return _Any()
+
+    def __iter__(self):
+        return iter(())
+
+    def __contains__(self, x):
+        return False
+
+    def __getitem__(self, k):
+        return _Any()
+
+
+def _stub_getattr(n):
+    if n.startswith("__"):                             # inspect.getmodule() probes __file__ of every module in sys.modules
+        raise AttributeError(n)
+    return _Any
+
+
+# imported by scene_synthesis/datasets (rendering, raw 3D-FRONT meshes, text generation) and absent here; none of them is touched by
+# the cached-dataset training path the script takes
+_SCRIPT_STUBS = ("trimesh", "simple_3dviz", "simple_3dviz.renderables", "simple_3dviz.renderables.textured_mesh", "simple_3dviz.behaviours",
+                 "simple_3dviz.behaviours.keyboard", "simple_3dviz.behaviours.misc", "torchtext", "num2words", "nltk", "nltk.tokenize",
+                 "nltk.corpus", "wandb")
+
+
+def prepare_reference_script_imports():
+    """Make ``import train_diffusion`` (the reference's scripts/train_diffusion.py, UNCHANGED) work in the build container with
+    ``scene_synthesis.networks`` / ``.stats_logger`` resolving to diffuscene_amd (diffuscene_amd.compat -- the documented drop-in
+    switch) and ``scene_synthesis.datasets`` to the REFERENCE's own package.  Returns the list of stubbed third-party modules."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    load_reference()                                   # tkinter stubs
+    made = []
+    for name in _SCRIPT_STUBS:
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except ImportError:
+                m = types.ModuleType(name)
+                m.__path__ = []
+                m.__getattr__ = _stub_getattr
+                sys.modules[name] = m
+                made.append(name)
+    from diffuscene_amd.compat import install_as_scene_synthesis
+    install_as_scene_synthesis(REF_ROOT)
+    scripts = os.path.join(REF_ROOT, "scripts")
+    if scripts not in sys.path:
+        sys.path.insert(0, scripts)
+    return made

@@ -1,0 +1,90 @@
+"""The reference's OWN training script -- /root/reference/scripts/train_diffusion.py, unchanged -- executed against this package on the
+CPU of the build container (missing item 6).  ``scene_synthesis.networks`` and ``.stats_logger`` resolve to diffuscene_amd
+through the documented switch (diffuscene_amd.compat.install_as_scene_synthesis); ``scene_synthesis.datasets`` is the REFERENCE's own
+package (its rendering / text / wandb imports stubbed, oracle/ref_loader.prepare_reference_script_imports) reading a synthetic cached
+3D-FRONT directory; the config is the reference's shipped YAML with only the site-specific paths edited.
+
+There is no GPU here and the product has no CPU path, so the two step functions ``build_network`` hands to the script are replaced by
+recorders (what the script passes them is checked against what the HIP step consumes: keys, shapes, dtypes, the target / condition the
+wrapper assembles from the batch); everything else the script touches is the product: argument parsing -> ``build_network`` signature and
+return value -> parameter counts -> ``optimizer_factory`` -> ``load_checkpoints`` -> ``schedule_factory`` -> ``StatsLogger`` ->
+``adjust_learning_rate`` -> the epoch loop -> ``save_checkpoints`` -> validation -> resuming from the checkpoints it wrote.
+The same sequence with the real step functions runs on the GPU in tests/test_gpu_plan.py (call for call, device input pipeline).
+Skipped where /root/reference does not exist (the GPU box)."""
+import copy
+import json
+import os
+import sys
+
+import pytest
+import torch
+import yaml
+
+from oracle import dataset_ref as DR
+from oracle.ref_loader import prepare_reference_script_imports, reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="the reference tree is only present in the build container")
+
+
+def test_real_train_diffusion_script_drives_the_package(tmp_path, golden_dir, monkeypatch):
+    prepare_reference_script_imports()
+    import scene_synthesis.networks as nets
+    import diffuscene_amd.networks as ours
+    assert nets is ours
+    root = str(tmp_path / "cached")
+    ids = DR.write_synth_cached_dataset(root, 40, seed=0, max_length=12)
+    with open(tmp_path / "splits.csv", "w") as f:
+        for i, sid in enumerate(ids):
+            f.write("%s,%s\n" % (sid, "test" if i % 5 == 4 else "train"))
+    cfgs = json.load(open(os.path.join(golden_dir, "reference_configs.json")))
+    config = copy.deepcopy(cfgs["uncond/diffusion_bedrooms_instancond_lat32_v.yaml"])
+    config["data"].update(dataset_directory=root, annotation_file=str(tmp_path / "splits.csv"), filter_fn="no_filtering")
+    config["network"]["diffusion_kwargs"]["train_stats_file"] = os.path.join(root, "dataset_stats.txt")
+    nc = DR.N_OBJECT_TYPES + 1                         # the synthetic store's object types + 'end' (the YAML's 22 = 21 + 1)
+    assert config["network"]["class_dim"] == nc        # the bedroom YAML as shipped
+    config["training"].update(epochs=2, batch_size=16, save_frequency=1)
+    config["validation"].update(frequency=1, batch_size=8)
+    cfg_path = tmp_path / "config.yaml"
+    cfg_path.write_text(yaml.safe_dump(config))
+
+    calls = {"train": [], "val": [], "models": []}
+
+    def rec_train(model, optimizer, sample_params, cfg):
+        assert cfg["training"]["max_grad_norm"] == 10 and optimizer.param_groups[0]["lr"] == 0.0002
+        target, condition, cross = model._loss_inputs(sample_params)           # the wrapper's batch assembly, on the script's batch
+        B = sample_params["class_labels"].shape[0]
+        assert tuple(target.shape) == (B, 12, 62) and target.dtype == torch.float32 and cross is None
+        assert tuple(condition.shape) == (B, 12, 128) and condition.stride(0) == 0
+        assert sample_params["class_labels"].shape[-1] == nc and sample_params["objfeats_32"].shape[-1] == 32
+        assert float(target[:, :, 8:8 + nc].abs().max()) == 1.0              # class labels arrive as -1 / +1
+        calls["train"].append(B)
+        calls["models"].append((model, model.training))
+        from scene_synthesis.stats_logger import StatsLogger
+        StatsLogger.instance()["loss.bbox"].value = 0.5
+        return 0.25
+
+    def rec_val(model, sample_params, cfg):
+        calls["val"].append(sample_params["class_labels"].shape[0])
+        return 0.125
+    monkeypatch.setattr(ours, "_train_on_batch", rec_train)
+    monkeypatch.setattr(ours, "_validate_on_batch", rec_val)
+    import train_diffusion
+    out = tmp_path / "out"
+    train_diffusion.main([str(cfg_path), str(out), "--experiment_tag", "exp", "--seed", "3"])
+    exp = out / "exp"
+    n_train = sum(1 for i in range(40) if i % 5 != 4)
+    assert calls["train"] == [16, 16] * 2 and sum(calls["train"][:2]) == n_train      # 2 epochs x (32 scenes / 16)
+    assert calls["val"] == [8]                                                          # epoch 1 validates (frequency 1, i > 0)
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    assert isinstance(calls["models"][0][0], DiffusionSceneLayout_DDPM) and all(tr for _, tr in calls["models"])
+    for name in ("params.json", "bounds.npz", "stats.txt", "model_00000", "opt_00000", "model_00001", "opt_00001"):
+        assert (exp / name).exists(), name
+    stats = (exp / "stats.txt").read_text()
+    assert "epoch: 1 - batch: 2 - loss: 0.25000 - loss.bbox: 0.50000" in stats and "epoch: -1 - batch: 1 - loss: 0.12500" in stats
+    sd = torch.load(str(exp / "model_00001"))
+    assert "positional_embedding" in sd and "diffusion.model.init_conv.weight" in sd
+    # a second run in the same experiment directory resumes from the checkpoints the first one wrote (load_checkpoints:
+    # model.load_state_dict + optimizer.load_state_dict with OUR optimizer's state_dict format) and has nothing left to do
+    calls["train"].clear()
+    train_diffusion.main([str(cfg_path), str(out), "--experiment_tag", "exp", "--seed", "3"])
+    assert calls["train"] == []
