@@ -527,7 +527,7 @@ static int select_tile(const dsc_gemm_args* a, bool gn) {
     constexpr long MIN_BLOCKS = 160;
     if (gn) {
         const int N = a->tokens_per_scene;
-        if (N <= 16 || N > 80) return -1;
+        if (N <= 16 || N > 80) return -1;            // (N <= 16: one-row-block tiles measured and rejected, profiles/r04_small_tiles.txt)
         const long S = a->m / N;
         if (N <= 32) return ((S + 3) / 4) * (a->n / 128) >= MIN_BLOCKS ? T_GN_32 : -1;
         const long b8 = wide ? ((S + 1) / 2) * (a->n / 256) : 0, b4 = ((S + 1) / 2) * (a->n / 128);

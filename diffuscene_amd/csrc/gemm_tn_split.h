@@ -62,7 +62,11 @@ struct Prob {
     long chunk, slab, bias_slab;
 };
 
-// it: 128-wide k tile, jt: 256-wide n tile, split: token slice
+// it: 128-wide k tile, jt: 256-wide n tile, split: token slice.
+// PROBE (tools/tn_probe.hip only; 0 = product): attribution variants that REMOVE one ingredient of the step (results are garbage) --
+// 1: no operand split (raw bits written as the three pieces), 2: no global loads, 3: no fragment reads (registers reused),
+// 4: 2 + 1 + no plane writes (MFMAs, fragment reads and the barrier only), 5: MFMAs and the barrier only.
+template <int PROBE = 0>
 __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, const int jt, const int split, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -108,6 +112,7 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
     float ld[NIT][8];
     auto load_item = [&](int u, int step) {
         const long mb = m_begin + (long)step * BMS;
+        if constexpr (PROBE == 2 || PROBE >= 4) return;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -120,7 +125,16 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
     auto store_item = [&](int u, char* stage, bool count) {
         if (do_bias && isdy[u] && count) bsum[u] += ((ld[u][0] + ld[u][1]) + (ld[u][2] + ld[u][3])) + ((ld[u][4] + ld[u][5]) + (ld[u][6] + ld[u][7]));
         bf16x8 a, b, c;
-        split8(ld[u], a, b, c);
+        if constexpr (PROBE >= 4) return;
+        if constexpr (PROBE == 1) {
+            u32x4 lo = {__builtin_bit_cast(unsigned, ld[u][0]), __builtin_bit_cast(unsigned, ld[u][1]), __builtin_bit_cast(unsigned, ld[u][2]),
+                        __builtin_bit_cast(unsigned, ld[u][3])};
+            u32x4 hi = {__builtin_bit_cast(unsigned, ld[u][4]), __builtin_bit_cast(unsigned, ld[u][5]), __builtin_bit_cast(unsigned, ld[u][6]),
+                        __builtin_bit_cast(unsigned, ld[u][7])};
+            a = __builtin_bit_cast(bf16x8, lo); b = __builtin_bit_cast(bf16x8, hi); c = a;
+        } else {
+            split8(ld[u], a, b, c);
+        }
         *reinterpret_cast<bf16x8*>(stage + ildso[u]) = a;
         *reinterpret_cast<bf16x8*>(stage + PLANE + ildso[u]) = b;
         *reinterpret_cast<bf16x8*>(stage + 2 * PLANE + ildso[u]) = c;
@@ -141,6 +155,19 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int NMMA = 24;                          // MFMAs per dy block (4 x blocks x 6 products)
+    bf16x8 pf_x[4][3], pf_d[3];                       // (probes 3 / 5 only: dead code in the product)
+    if constexpr (PROBE != 0) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ld[u][e] = (float)(tid + e) * 1e-3f;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            pf_d[pl] = *reinterpret_cast<const bf16x8*>(smem + pl * PLANE + doff[0]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) pf_x[b][pl] = *reinterpret_cast<const bf16x8*>(smem + pl * PLANE + xoff[b]);
+        }
+    }
     if (steps > 0) {
 #pragma unroll
         for (int u = 0; u < NIT; ++u) load_item(u, 0);
@@ -160,16 +187,26 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
         const bool more = s + 1 < steps;
         const int s2 = s + 2 < steps ? s + 2 : steps - 1;
         bf16x8 xf[4][3], df[2][3];
+        constexpr bool NOFRAG = PROBE == 3 || PROBE == 5;
+        if constexpr (NOFRAG) {               // probe: the fragments of step 0 stay in registers, no LDS read traffic in the loop
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
+            for (int pl = 0; pl < 3; ++pl) { df[0][pl] = pf_d[pl]; df[1][pl] = pf_d[pl]; }
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
+                for (int pl = 0; pl < 3; ++pl) xf[b][pl] = pf_x[b][pl];
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            if (nb + 1 < 4) {
+            if (nb + 1 < 4 && !NOFRAG) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
             }

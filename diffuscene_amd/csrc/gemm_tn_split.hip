@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc
         p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
         p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
     }
-    dsc_tn_split::tn_split_block(p, local % ktiles, local / ktiles, split, smem);
+    dsc_tn_split::tn_split_block<0>(p, local % ktiles, local / ktiles, split, smem);
 }
 
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,

@@ -35,7 +35,11 @@ def check(a, b, what, tol=TOL):
     r = float((a - b).abs().max() / bmax)
     ew = float(((a - b).abs() / torch.clamp(b.abs(), min=5e-2 * bmax)).max())
     strict = float((((a - b).abs() <= 1e-4 * torch.clamp(b.abs(), min=1e-3)).double()).mean())
-    print("%s: norm-relative %.3g, element-wise %.3g (%.2f%% of elements within 1e-4*max(|b|,1e-3))" % (what, r, ew, 100 * strict))
+    line = "%s: norm-relative %.3g, element-wise %.3g (%.2f%% of elements within 1e-4*max(|b|,1e-3))" % (what, r, ew, 100 * strict)
+    print(line)
+    if os.environ.get("DSC_PARITY_LOG"):              # tools/gpu_round.sh: the measured distances of a run, kept under profiles/
+        with open(os.environ["DSC_PARITY_LOG"], "a") as f:
+            f.write(line + "\n")
     assert r < tol and ew < tol, (what, r, ew)
 
 

@@ -10,7 +10,7 @@ mkdir -p $O
 cd $R
 for s in $STEPS; do
 case $s in
-tests) timeout 1800 python -m pytest tests -m gpu -q --durations=15 > $O/${TAG}_tests.log 2>&1; tail -40 $O/${TAG}_tests.log | grep -v "^$" | tail -30 ;;
+tests) rm -f $O/${TAG}_parity.txt; DSC_PARITY_LOG=$O/${TAG}_parity.txt timeout 1800 python -m pytest tests -m gpu -q --durations=15 > $O/${TAG}_tests.log 2>&1; tail -40 $O/${TAG}_tests.log | grep -v "^$" | tail -30 ;;
 twolayer) timeout 300 python tools/two_layer_probe.py > $O/${TAG}_two_layer.txt 2>&1; cat $O/${TAG}_two_layer.txt | tail -14 ;;
 smoke) timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -1 $O/${TAG}_smoke.log ;;
 bench) timeout 600 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -1 $O/${TAG}_bench_default.json | cut -c1-600 ;;
