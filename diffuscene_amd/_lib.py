@@ -134,7 +134,7 @@ SIGNATURES = {
     "dsc_gemm_tn_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "dsc_gemm_tn_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_int64,
                                           C.c_void_p]),
-    "dsc_gemm_tn_grouped_split_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64,
+    "dsc_gemm_tn_grouped_split_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, c_f32p, C.c_int64,
                                                 C.c_int64, C.c_void_p]),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

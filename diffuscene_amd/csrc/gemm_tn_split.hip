@@ -4,26 +4,24 @@
 #include "gemm_tn_split.h"
 
 // The same grouped weight-gradient launch on the bf16 matrix cores (gemm_tn_split.h: operands split exactly into three bf16 pieces,
-// six products, f32 accumulation -- error vs f64 <= the f32-MFMA kernel's, ~1.6x faster).  Tiles are 256 (n) x 128 (k): groups
-// carry a second tile numbering (tile0s); the slab reduction is the f32 form's (128 x 128 tiles, tile0).
-__device__ __forceinline__ int tn_find_group_s(const dsc_tn_group* __restrict__ g, int count, int tile) {
-    int lo = 0, hi = count - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (g[mid].tile0s <= tile) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-__global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int count,
+// six products, f32 accumulation -- error vs f64 <= the f32-MFMA kernel's, ~1.6x faster).  Tiles are 256 (n) x 128 (k), addressed
+// through the host's block map (below); the slab reduction is the f32 form's (128 x 128 tiles, tile0).
+// Block placement (round 4).  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own 4 MB L2, and the
+// 256 x 128 tiles of one layer share its operand strips (a 512 x 512 dW: 8 tiles, every dY strip read by 4 of them, every A strip by 2).
+// With tiles numbered layer by layer a layer's tiles sat on 8 DIFFERENT L2s and every strip crossed the fabric once per tile (measured
+// round 3: 9.1 GB fetched per launch, 3x the operands).  The host now hands the kernel a block map -- physical block id -> (group, tile
+// of the group) -- that puts the tiles of one layer on ONE XCD (ids congruent mod 8), long layers first on every XCD, the short groups'
+// tiles dealt out evenly (train_plan.tn_block_map); (-1, -1) pads the XCD lists to one length.  tools/tn_probe.py, same step, 256
+// blocks: 1632 -> 1564 us (-4.2 %; all strips hot in every L2: 1520).
+__global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int2* __restrict__ block_map,
                                                                        const int splits, float* __restrict__ workspace) {
     __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::SMEM];
-    const int tile = blockIdx.x;
-    const int gi = tn_find_group_s(groups, count, tile);
-    const dsc_tn_group g = groups[gi];
+    const int2 gt = block_map[blockIdx.x];
+    if (gt.x < 0) return;
+    const dsc_tn_group g = groups[gt.x];
     const int K = g.k1 + g.k2;
     const int ktiles = (K + 127) / 128;
-    const int local = tile - g.tile0s;
+    const int local = gt.y;
     const int split = blockIdx.y;
     dsc_tn_split::Prob p;
     p.a1 = g.a1; p.lda1 = g.lda1; p.k1 = g.k1; p.a2 = g.a2; p.lda2 = g.lda2; p.k2 = g.k2; p.dy = g.dy; p.ldd = g.ldd;
@@ -40,16 +38,16 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc
 }
 
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
-                                             int32_t total_tiles_split, int32_t splits, float* workspace, int64_t workspace_floats,
-                                             int64_t workspace_needed, dsc_stream_t stream) {
-    if (!groups_dev || count < 1 || total_tiles < count || total_tiles_split < count || splits < 1 || splits > 64) return DSC_EINVAL;
+                                             const int32_t* block_map_dev, int32_t blocks, int32_t splits, float* workspace,
+                                             int64_t workspace_floats, int64_t workspace_needed, dsc_stream_t stream) {
+    if (!groups_dev || !block_map_dev || count < 1 || total_tiles < count || blocks < count || splits < 1 || splits > 64) return DSC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(block_map_dev) & 7) return DSC_EALIGN;
     if (splits > 1 && (!workspace || workspace_floats < workspace_needed || workspace_needed < 1)) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)total_tiles_split, (unsigned)splits), dim3(512), 0, s, groups_dev,
-                       count, splits, workspace);
+    hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(512), 0, s, groups_dev,
+                       reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
     DSC_LAUNCH_CHECK();
     if (splits > 1) return dsc_launch_reduce_grouped(groups_dev, count, total_tiles, splits, workspace, s);
     return 0;
 }
-

@@ -66,6 +66,45 @@ def tn_token_slices(groups, tile_n, blocks_target):
     return max(1, min(32, m_ref // 256, -(-blocks_target // max(long_tiles, 1)))), m_ref
 
 
+def tn_block_map(groups, n_xcd=8):
+    """Block placement of one grouped weight-gradient launch on the split-bf16 kernel (256 x 128 tiles).
+    groups: (m tokens, n, k) per group, in table order.  -> list of (group, tile of the group) per PHYSICAL block id, (-1, -1) = idle.
+
+    Consecutive workgroup ids are dealt round-robin over the XCDs (id % 8), each with its own L2, and the tiles of one layer share its
+    operand strips -- so every "long" group (one that carries the launch: at least half the reference token length of tn_token_slices)
+    goes WHOLE to one XCD, longest first, always to the XCD with the least work so far; the tiles of the remaining groups (the packed
+    time-MLP gradient: 1216 tiles over 256 tokens; tiny conditioning layers) are dealt one by one to the emptiest XCD, behind the
+    long ones.  Every XCD then walks its list in order: physical block b = 8 * position + xcd."""
+    def tiles(n, k):
+        return ((n + 255) // 256) * ((k + 127) // 128)
+    _, m_ref = tn_token_slices(groups, 256, 768)
+    lists = [[] for _ in range(n_xcd)]
+    work = [0] * n_xcd                                   # token steps queued per XCD
+    order = sorted(range(len(groups)), key=lambda i: (-groups[i][0], -tiles(groups[i][1], groups[i][2]), i))
+    short = []
+    for gi in order:
+        m, n, k = groups[gi]
+        nt = tiles(n, k)
+        if 2 * m >= m_ref and nt <= 64:
+            x = min(range(n_xcd), key=lambda j: (work[j], j))
+            lists[x].extend((gi, t) for t in range(nt))
+            work[x] += nt * m
+        else:
+            short.append(gi)
+    for gi in short:
+        m, n, k = groups[gi]
+        for t in range(tiles(n, k)):
+            x = min(range(n_xcd), key=lambda j: (work[j], j))
+            lists[x].append((gi, t))
+            work[x] += m
+    depth = max(len(l) for l in lists)
+    out = []
+    for pos in range(depth):
+        for x in range(n_xcd):
+            out.append(lists[x][pos] if pos < len(lists[x]) else (-1, -1))
+    return out
+
+
 class HipBackend:
     """Lowers plan ops to (cfunc, args) launches of libdiffuscene_hip.so with pointers fixed at build time."""
 
@@ -324,10 +363,13 @@ class HipBackend:
                     arr[i].ws_offset = ws_off
                     ws_off += (n * kv + n) * splits
             table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
-            self.keep.append((table, items))
+            bmap = np.asarray(tn_block_map(shapes), dtype=np.int32).reshape(-1, 2)
+            assert int((bmap[:, 0] >= 0).sum()) == tile0s, "block map must cover every 256 x 128 tile exactly once"
+            bmap_dev = torch.from_numpy(bmap.copy()).to(self.device)
+            self.keep.append((table, items, bmap_dev))
             fn = self.lib.fn("dsc_gemm_tn_grouped_split_f32")
-            tp, cnt, total_s = table.data_ptr(), len(items), tile0s
-            return self._with_scratch(ws_off, lambda wp, wn: (fn, (tp, cnt, total, total_s, splits, wp if splits > 1 else None,
+            tp, cnt, bp, nblk = table.data_ptr(), len(items), bmap_dev.data_ptr(), bmap.shape[0]
+            return self._with_scratch(ws_off, lambda wp, wn: (fn, (tp, cnt, total, bp, nblk, splits, wp if splits > 1 else None,
                                                                     wn if splits > 1 else 0, ws_off), "dsc_gemm_tn_grouped_split_f32"))
         # the long tiles set the duration: cut the tokens until they make ~8 rounds of 2 blocks per CU (tail < 1/8); with all
         # layers of a step in one group that is 2 slabs per gradient instead of the 32 of a per-layer launch

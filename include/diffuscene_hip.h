@@ -247,16 +247,19 @@ typedef struct dsc_tn_group {
     int32_t m, n, kvalid;
     int32_t tile0;
     int64_t ws_offset;
-    int32_t tile0s;   /* first tile of the group in the 256 (n) x 128 (k) numbering of dsc_gemm_tn_grouped_split_f32 */
+    int32_t tile0s;   /* reserved (round 3: first tile in the 256 x 128 numbering; the split launch now takes a block map) */
 } dsc_tn_group;
 int dsc_gemm_tn_grouped_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, int32_t splits,
                             float* workspace, int64_t workspace_floats, int64_t workspace_needed, dsc_stream_t stream);
 /* The same launch on the bf16 matrix cores with f32 accuracy (both operands split exactly into three bf16 pieces, six products, f32
- * accumulation; csrc/gemm_tn_split.h).  Output tiles are 256 x 128: total_tiles_split = sum over groups of
- * ceil(n / 256) * ceil((k1 + k2) / 128), tile0s = the group's first tile in that numbering; total_tiles / tile0 stay the 128 x 128
- * numbering (used by the slab reduction when splits > 1).  Every operand must satisfy m * ld * 4 < 2^31. */
-int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, int32_t total_tiles_split,
-                                  int32_t splits, float* workspace, int64_t workspace_floats, int64_t workspace_needed,
+ * accumulation; csrc/gemm_tn_split.h).  Output tiles are 256 (n) x 128 (k); the caller supplies the block placement:
+ *   block_map_dev  DEVICE array of `blocks` int32 pairs (group index, tile of that group: k tile + ktiles * n tile), 8-byte aligned;
+ *                  (-1, -1) = idle block.  Every tile of every group must appear exactly once.  Consecutive workgroup ids are dealt
+ *                  round-robin over the 8 XCDs, so entries b, b + 8, b + 16 ... share one L2: put the tiles of one layer there.
+ * total_tiles / tile0 stay the 128 x 128 numbering (used by the slab reduction when splits > 1; tile0s is unused).  Every operand must
+ * satisfy m * ld * 4 < 2^31. */
+int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, const int32_t* block_map_dev,
+                                  int32_t blocks, int32_t splits, float* workspace, int64_t workspace_floats, int64_t workspace_needed,
                                   dsc_stream_t stream);
 
 /* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */

@@ -74,5 +74,59 @@ def test_text_training_plan_builds_on_the_host_with_short_slice_counts(tmp_path,
     tb = {n: getattr(d, n).float() for n in d._TABLE_NAMES}
     plan = train_plan.TrainPlan(net, flat, d, 128, 12, SS_PER_SLOT, 128, 32, 512, train_plan.HipBackend(torch.device("cpu")), tables=tb)
     assert len(plan.fwd) > 150 and len(plan.bwd) > 250
-    assert chosen == [(135, (1, 1536))], chosen
+    assert chosen and all(c == (135, (1, 1536)) for c in chosen), chosen      # (the block map asks the same rule for the reference length)
     assert plan.n_adds == 8              # only the 8 skip-connection adds are left (round 3: 8 + one per LayerNorm input)
+
+
+def test_block_map_puts_a_layers_tiles_on_one_xcd_and_covers_every_tile_once():
+    """train_plan.tn_block_map: physical block b runs on XCD b % 8 (consecutive workgroup ids are dealt round-robin over the XCDs); the
+    tiles of one long layer share its operand strips, so they must share one L2; short groups fill in behind, evenly."""
+    from diffuscene_amd.train_plan import tn_block_map
+    # the headline plan's launch: 59 layers of 8 tiles, 30 of 16, 3 of 4 over 20480 tokens; the packed time MLP (1216 tiles, 256 tokens)
+    groups = [(20480, 512, 512)] * 59 + [(20480, 512, 1024)] * 30 + [(20480, 512, 256)] * 3 + [(256, 19456, 2048)] + [(80, 9216, 128)]
+    bm = tn_block_map(groups)
+    assert len(bm) % 8 == 0
+
+    def tiles(n, k):
+        return ((n + 255) // 256) * ((k + 127) // 128)
+    seen = {}
+    for b, (g, t) in enumerate(bm):
+        if g < 0:
+            assert t < 0
+            continue
+        assert (g, t) not in seen and 0 <= t < tiles(groups[g][1], groups[g][2])
+        seen[(g, t)] = b
+    assert len(seen) == sum(tiles(n, k) for _, n, k in groups)
+    for g, (m, n, k) in enumerate(groups):
+        xcds = {seen[(g, t)] % 8 for t in range(tiles(n, k))}
+        if m == 20480:
+            assert len(xcds) == 1, "a long layer's tiles must sit on one XCD"
+            pos = sorted(seen[(g, t)] // 8 for t in range(tiles(n, k)))
+            assert pos == list(range(pos[0], pos[0] + len(pos))), "... back to back in that XCD's list"
+        elif tiles(n, k) >= 64:
+            assert len(xcds) >= 6                     # dealt to the emptiest XCDs, wherever the long layers left room
+    # every XCD carries the same token work to within one long layer, and the long layers come first on each of them
+    work = [0] * 8
+    first_short = [None] * 8
+    last_long = [0] * 8
+    for b, (g, t) in enumerate(bm):
+        if g < 0:
+            continue
+        x = b % 8
+        work[x] += groups[g][0]
+        if groups[g][0] == 20480:
+            last_long[x] = b // 8
+        elif first_short[x] is None:
+            first_short[x] = b // 8
+    assert max(work) - min(work) <= 16 * 20480
+    assert all(fs is None or fs > ll for fs, ll in zip(first_short, last_long))
+    idle = sum(1 for g, _ in bm if g < 0)
+    assert idle < len(bm) // 8                          # padding (idle blocks return at once): XCDs with fewer long tiles hold more short ones
+
+
+def test_block_map_small_launches():
+    from diffuscene_amd.train_plan import tn_block_map
+    assert tn_block_map([(1290, 512, 512)]) == [(0, t) if x == 0 else (-1, -1) for t in range(8) for x in range(8)]
+    bm = tn_block_map([(64, 1024, 512), (1290, 32, 512)])            # 16 short tiles + 4 long: long first on XCD 0, short dealt around
+    assert sorted(gt for gt in bm if gt[0] >= 0) == sorted([(0, t) for t in range(16)] + [(1, t) for t in range(4)])
+    assert [bm[8 * i] for i in range(4)] == [(1, 0), (1, 1), (1, 2), (1, 3)]

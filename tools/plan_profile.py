@@ -47,7 +47,8 @@ for idx, (f, a) in enumerate(steps):
     us = sorted(e0.elapsed_time(e1) * 500.0 for e0, e1 in evs)[REPS // 2]
     desc, fl = f.__name__, 0.0
     if f.__name__ in ("dsc_gemm_tn_grouped_f32", "dsc_gemm_tn_grouped_split_f32"):
-        desc = "%s groups=%s tiles=%s splits=%s" % (f.__name__, a[1], a[3] if "split" in f.__name__ else a[2], a[4] if "split" in f.__name__ else a[3])
+        desc = "%s groups=%s %s splits=%s" % (f.__name__, a[1], ("blocks=%s" % a[4]) if "split" in f.__name__ else ("tiles=%s" % a[2]),
+                                             a[5] if "split" in f.__name__ else a[3])
     if f is gemm_f or f is gn_f:
         g = a[0]._obj
         fl = 2.0 * g.m * g.n * (g.k1 + g.k2) * max(g.batch, 1)

@@ -27,7 +27,7 @@ def main():
     import torch
     lib = C.CDLL(SO)
     lib.tn_probe.restype = C.c_int
-    lib.tn_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.tn_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     dev = torch.device("cuda:0")
     m, n, k, layers = 20480, 512, 512, 32
     a = torch.randn(layers, m, k, device=dev)
@@ -35,8 +35,8 @@ def main():
     out = torch.empty(layers, n, k, device=dev)
     s = torch.cuda.current_stream().cuda_stream
 
-    def run(p):
-        rc = lib.tn_probe(p, a.data_ptr(), dy.data_ptr(), out.data_ptr(), m, n, k, layers, s)
+    def run(p, map_=0):
+        rc = lib.tn_probe(p, a.data_ptr(), dy.data_ptr(), out.data_ptr(), m, n, k, layers, map_, s)
         assert rc == 0, rc
     run(0)
     torch.cuda.synchronize()
@@ -64,6 +64,26 @@ def main():
     for p, ts in times.items():
         med = sorted(ts)[len(ts) // 2]
         print("%-42s %10.1f %16.0f" % ("%d: %s" % (p, NAMES[p]), med, med * 2000.0 / steps))
+    # block -> XCD placement of the PRODUCT step (tools/tn_probe.hip): a layer's 8 tiles on 8 different L2s / on one L2 / all strips hot
+    maps = {0: "consecutive ids (product order): a layer's tiles on 8 XCDs", 1: "XCD-grouped: a layer's tiles share one L2",
+            2: "all blocks on layer 0 (cache-hit bound)"}
+    run(0, 1)
+    torch.cuda.synchronize()
+    assert float((out[:2].double() - ref).abs().max() / ref.abs().max()) < 5e-6
+    mt = {k_: [] for k_ in maps}
+    for r in range(7):
+        for k_ in list(maps)[r % 3:] + list(maps)[:r % 3]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                run(0, k_)
+            e1.record()
+            torch.cuda.synchronize()
+            mt[k_].append(e0.elapsed_time(e1) * 250.0)
+    print("\nblock placement (product step):")
+    for k_, ts in mt.items():
+        med = sorted(ts)[len(ts) // 2]
+        print("  map %d %-62s %8.1f us %8.0f cycles/step" % (k_, maps[k_], med, med * 2000.0 / steps))
     fl = 2.0 * m * n * k * layers
     print("\nproduct: %.1f TFLOP/s algorithmic (%.0f executed); MFMA issue floor 3072 cycles per step" % (
         fl / sorted(times[0])[3] / 1e6, 6 * fl / sorted(times[0])[3] / 1e6))
