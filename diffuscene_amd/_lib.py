@@ -54,6 +54,18 @@ class SplitItem(C.Structure):
                 ("transpose", C.c_int32)]
 
 
+class SmallKItem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("k_in", C.c_int32), ("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p),
+                ("y", C.c_void_p), ("ldy", C.c_int64)]
+
+
+class ColSpan(C.Structure):
+    _fields_ = [("src_col", C.c_int32), ("dst_col", C.c_int32), ("width", C.c_int32)]
+
+
+SMALLK_MAX = 4
+
+
 class WsItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
@@ -91,6 +103,8 @@ SIGNATURES = {
     "dsc_gemm_splitk_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_int32, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_linear_smallk_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dsc_linear_smallk_grouped_f32": (C.c_int, [C.POINTER(SmallKItem), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "dsc_gather_columns_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.POINTER(ColSpan), C.c_int32, C.c_void_p]),
     "dsc_weight_standardize_f32": (C.c_int, [C.POINTER(WsItem), C.c_int32, C.c_float, C.c_void_p]),
     "dsc_layernorm_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
                                     C.c_int32, C.c_float, C.c_void_p]),

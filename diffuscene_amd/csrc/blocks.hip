@@ -286,11 +286,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 constexpr int SK_TOK = 32;
 constexpr int SK_MAXK = 64;
 
-__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ x, int64_t ldx, int kin,
-                                                            const float* __restrict__ w, int64_t ldw,
-                                                            const float* __restrict__ bias,
-                                                            float* __restrict__ y, int64_t ldy, int m, int n, int act) {
-    __shared__ float xs[SK_MAXK * SK_TOK];
+__device__ __forceinline__ void linear_smallk_block(const float* __restrict__ x, int64_t ldx, int kin,
+                                                    const float* __restrict__ w, int64_t ldw,
+                                                    const float* __restrict__ bias,
+                                                    float* __restrict__ y, int64_t ldy, int m, int n, int act, float* xs) {
     const int tok0 = blockIdx.x * SK_TOK;
     const int ntok = (m - tok0) < SK_TOK ? (m - tok0) : SK_TOK;
     for (int f = threadIdx.x; f < SK_TOK * kin; f += 256) {
@@ -325,6 +324,41 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t < SK_TOK; ++t)
             if (t < ntok) y[(int64_t)(tok0 + t) * ldy + c] = dsc_act(acc[t], act);
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ x, int64_t ldx, int kin,
+                                                            const float* __restrict__ w, int64_t ldw,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ y, int64_t ldy, int m, int n, int act) {
+    __shared__ float xs[SK_MAXK * SK_TOK];
+    linear_smallk_block(x, ldx, kin, w, ldw, bias, y, ldy, m, n, act, xs);
+}
+
+// the first layers of ALL per-attribute encoders in one launch (blockIdx.y = head): 3-4 x the blocks of a single head in flight
+struct SmallKBatch { dsc_smallk_item it[DSC_SMALLK_MAX]; };
+__global__ __launch_bounds__(256) void linear_smallk_grouped_kernel(const SmallKBatch b, int m, int n, int act) {
+    __shared__ float xs[SK_MAXK * SK_TOK];
+    const dsc_smallk_item it = b.it[blockIdx.y];
+    linear_smallk_block(it.x, it.ldx, it.k_in, it.w, it.ldw, it.bias, it.y, it.ldy, m, n, act, xs);
+}
+
+// dst[r][span.dst_col + c] = src[r][span.src_col + c], c < span.width, for a few column spans (the padded outputs of the stacked
+// decoder heads -> the (M, C) scene tensor)
+struct ColSpans { dsc_col_span sp[DSC_SMALLK_MAX]; int count; int total; };
+__global__ __launch_bounds__(256) void gather_columns_kernel(float* __restrict__ dst, int64_t ldd, const float* __restrict__ src, int64_t lds,
+                                                             int rows, const ColSpans cs) {
+    const long n = (long)rows * cs.total;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cs.total;
+        int c = (int)(i - r * cs.total);
+#pragma unroll
+        for (int k = 0; k < DSC_SMALLK_MAX; ++k) {
+            if (k < cs.count) {
+                if (c >= 0 && c < cs.sp[k].width) dst[r * ldd + cs.sp[k].dst_col + c] = src[r * lds + cs.sp[k].src_col + c];
+                c -= cs.sp[k].width;
+            }
+        }
     }
 }
 
@@ -430,6 +464,42 @@ extern "C" int dsc_linear_smallk_f32(const float* x, int64_t ldx, int32_t k_in, 
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(linear_smallk_kernel, dim3((m + SK_TOK - 1) / SK_TOK), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, k_in, w, ldw, bias, y, ldy, m, n, act_out);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_linear_smallk_grouped_f32(const dsc_smallk_item* items, int32_t count, int32_t m, int32_t n, int32_t act_out,
+                                             dsc_stream_t stream) {
+    if (!items || count < 1 || count > DSC_SMALLK_MAX || m < 1 || n < 1) return DSC_EINVAL;
+    SmallKBatch b;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].x || !items[i].w || !items[i].y || items[i].k_in < 1) return DSC_EINVAL;
+        if (items[i].k_in > SK_MAXK) return DSC_ERANGE;
+        b.it[i] = items[i];
+    }
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(linear_smallk_grouped_kernel, dim3((m + SK_TOK - 1) / SK_TOK, count), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), b, m, n, act_out);
+    DSC_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dsc_gather_columns_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, const dsc_col_span* spans,
+                                      int32_t count, dsc_stream_t stream) {
+    if (!dst || !src || !spans || rows < 1 || count < 1 || count > DSC_SMALLK_MAX) return DSC_EINVAL;
+    ColSpans cs;
+    cs.count = count;
+    cs.total = 0;
+    for (int i = 0; i < count; ++i) {
+        if (spans[i].width < 1 || spans[i].src_col < 0 || spans[i].dst_col < 0) return DSC_EINVAL;
+        cs.sp[i] = spans[i];
+        cs.total += spans[i].width;
+    }
+    long blocks = ((long)rows * cs.total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    DSC_CLEAR_STALE_ERROR();
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dst, ldd, src, lds,
+                       rows, cs);
     DSC_LAUNCH_CHECK();
     return 0;
 }

@@ -19,6 +19,7 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, SS_BY_INDEX, SS_NONE, SS_PER_SCE
 
 D = 512
 HID = 128
+DEC_PAD = 32        # rows per head of the stacked, zero-padded decoder output projections (bbox 8, class <= 32, objfeat 32)
 
 
 class _Pool:
@@ -97,7 +98,11 @@ class Plan:
         stacked = w._base if w._base is not None else w
         g = ops.make_gemm_args(a, w, out, bias, None, None, ACT_NONE, act_out)
         g.batch, g.sa1, g.sw, g.sy, g.sbias = batch, sa, sw, sy, sbias
-        pl = self.eng.planes_of(stacked) if (stacked.shape[0] == batch * w.shape[0] and ops.gemm_would_use_split(g)) else None
+        # the kernel indexes the planes as [(z n + col) K] from the START of the stack: `w` must be its first row block, the stack a
+        # dense [batch n][K] matrix and the problem stride one block; anything else multiplies on the f32 kernel
+        whole = (stacked.dim() == 2 and stacked.is_contiguous() and w.data_ptr() == stacked.data_ptr()
+                 and stacked.shape[0] == batch * w.shape[0] and stacked.shape[1] == w.shape[1] and sw == w.shape[0] * w.shape[1])
+        pl = self.eng.planes_of(stacked) if (whole and ops.gemm_would_use_split(g)) else None
         if pl is not None:
             g.w_planes = pl.data_ptr()
         self.keep.append((g, a, w, out, bias, pl))
@@ -267,10 +272,15 @@ class Plan:
             emb = pool.get(M, D)
             H = len(e.enc_heads)
             h1 = pool.get(M, H * D)
-            for i, (seq, c0, k) in enumerate(e.enc_heads):            # layer 1: tiny K on un-aligned column slices
+            # layer 1: tiny K on un-aligned column slices -- all heads in ONE launch (round 4: three launches of 22-40 us, each too
+            # short to fill the chip; bit-identical results)
+            items = (_lib.SmallKItem * H)()
+            for i, (seq, c0, k) in enumerate(e.enc_heads):
                 xs = self.x_in[:, c0:c0 + k]
-                self.call("dsc_linear_smallk_f32", xs.data_ptr(), self.x_in.stride(0), k, seq[0].weight.data_ptr(), k,
-                          seq[0].bias.data_ptr(), h1.data_ptr() + 4 * i * D, H * D, M, D, ACT_GELU, keep=(xs, h1))
+                items[i].x, items[i].ldx, items[i].k_in = xs.data_ptr(), self.x_in.stride(0), k
+                items[i].w, items[i].ldw, items[i].bias = seq[0].weight.data_ptr(), k, seq[0].bias.data_ptr()
+                items[i].y, items[i].ldy = h1.data_ptr() + 4 * i * D, H * D
+            self.call("dsc_linear_smallk_grouped_f32", items, H, M, D, ACT_GELU, keep=(items, h1))
             h2 = pool.get(M, H * 2 * D)
             self.gemm_batched(h1[:, :D], e.enc_w2[:2 * D], h2[:, :2 * D], e.enc_b2[:2 * D], H, D, 2 * D * D, 2 * D, 2 * D,
                               act_out=ACT_GELU)
@@ -351,10 +361,19 @@ class Plan:
             d2 = pool.get(M, Hd * D)
             self.gemm_batched(d1[:, :2 * D], e.dec_w2[:D], d2[:, :D], e.dec_b2[:D], Hd, 2 * D, D * 2 * D, D, D, act_out=ACT_GELU)
             pool.put(d1)
+            # layer 3: the narrow output projections (8 / 25 / 32 columns) as ONE batched launch on weights zero-padded to DEC_PAD rows
+            # per head, into a padded [M, Hd * DEC_PAD] buffer, then one gather into the heads' columns of the (M, C) output (round 4:
+            # three launches of 25-28 us for 0.05 % of the flops; the products of the valid rows are unchanged: same kernel, same tile)
+            pad = pool.get(M, Hd * DEC_PAD)
+            self.gemm_batched(d2[:, :D], e.dec_w3p[:DEC_PAD], pad[:, :DEC_PAD], e.dec_b3p[:DEC_PAD], Hd, D, DEC_PAD * D, DEC_PAD, DEC_PAD)
+            spans = (_lib.ColSpan * Hd)()
             col = 0
-            for i, (seq, width) in enumerate(e.dec_heads):            # layer 3: narrow outputs at their column offsets
-                self.gemm(d2[:, i * D:(i + 1) * D], seq[4].weight, self.out[:, col:col + width], seq[4].bias)
+            for i, (seq, width) in enumerate(e.dec_heads):
+                spans[i].src_col, spans[i].dst_col, spans[i].width = i * DEC_PAD, col, width
                 col += width
+            self.call("dsc_gather_columns_f32", self.out.data_ptr(), self.out.stride(0), pad.data_ptr(), pad.stride(0), M, spans, Hd,
+                      keep=(spans, pad))
+            pool.put(pad)
             pool.put(d2)
         else:
             self.gemm(x, net.final_conv.weight, self.out, net.final_conv.bias)
@@ -432,6 +451,9 @@ class DenoiserEngine:
             self.dec_b1 = torch.empty((Hd * 2 * D,), device=device)
             self.dec_w2 = torch.empty((Hd * D, 2 * D), device=device)
             self.dec_b2 = torch.empty((Hd * D,), device=device)
+            assert all(width <= DEC_PAD for _, width in self.dec_heads)
+            self.dec_w3p = torch.zeros((Hd * DEC_PAD, D), device=device)      # output projections, zero-padded to DEC_PAD rows each
+            self.dec_b3p = torch.zeros((Hd * DEC_PAD,), device=device)
 
     def planes_of(self, w):
         """bf16 planes (3, n, K) of a weight the plans multiply with (None where the split path does not apply).  The entry is
@@ -487,6 +509,8 @@ class DenoiserEngine:
                     self.dec_b1[i * H2:(i + 1) * H2].copy_(seq[0].bias)
                     self.dec_w2[i * D:(i + 1) * D].copy_(seq[2].weight.view(D, H2))
                     self.dec_b2[i * D:(i + 1) * D].copy_(seq[2].bias)
+                    self.dec_w3p[i * DEC_PAD:i * DEC_PAD + width].copy_(seq[4].weight.view(width, D))
+                    self.dec_b3p[i * DEC_PAD:i * DEC_PAD + width].copy_(seq[4].bias)
             if self._planes:
                 ops.split_planes([(w2, planes, False) for w2, planes in self._planes.values()])
         self.sig = sig

@@ -245,6 +245,36 @@ def time_embedding(t, dim, table, freq, out=None):
     return out
 
 
+def linear_smallk_grouped(xs, ws, biases, outs, act_out=ACT_NONE):
+    """``len(xs)`` <= 4 small-K linears of one output width in ONE launch (dsc_linear_smallk_grouped_f32): xs[i] [m, k_i] may be column
+    slices of a wider tensor, outs[i] [m, n] column blocks of a wider buffer."""
+    n_items = len(xs)
+    items = (_lib.SmallKItem * n_items)()
+    m, n = outs[0].shape
+    for i in range(n_items):
+        w2 = as2d(ws[i])
+        items[i].x, items[i].ldx = _mat(xs[i], "x")
+        items[i].k_in = xs[i].shape[1]
+        items[i].w, items[i].ldw = _mat(w2, "w")
+        items[i].bias = biases[i].data_ptr() if biases[i] is not None else None
+        items[i].y, items[i].ldy = _mat(outs[i], "y")
+        if tuple(outs[i].shape) != (m, n) or w2.shape[0] != n or xs[i].shape[0] != m:
+            raise RuntimeError("linear_smallk_grouped: every head must produce the same [m, n] block")
+    _lib.check(_lib.fn("dsc_linear_smallk_grouped_f32")(items, n_items, m, n, act_out, stream_ptr()), "dsc_linear_smallk_grouped_f32")
+    return outs
+
+
+def gather_columns(dst, src, spans):
+    """dst[:, d:d+w] = src[:, s:s+w] for (s, d, w) in spans (<= 4), one launch."""
+    arr = (_lib.ColSpan * len(spans))()
+    for i, (sc, dc, w) in enumerate(spans):
+        arr[i].src_col, arr[i].dst_col, arr[i].width = sc, dc, w
+    dp, ldd = _mat(dst, "dst")
+    sp, lds = _mat(src, "src")
+    _lib.check(_lib.fn("dsc_gather_columns_f32")(dp, ldd, sp, lds, dst.shape[0], arr, len(spans), stream_ptr()), "dsc_gather_columns_f32")
+    return dst
+
+
 def activation(x, act, out=None):
     _dev(x)
     if not x.is_contiguous():

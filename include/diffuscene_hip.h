@@ -138,6 +138,19 @@ int dsc_gemm_layernorm_f32(const dsc_gemm_args* a, dsc_stream_t stream);
 int dsc_linear_smallk_f32(const float* x, int64_t ldx, int32_t k_in, const float* w, int64_t ldw,
                           const float* bias, float* y, int64_t ldy, int32_t m, int32_t n,
                           int32_t act_out, dsc_stream_t stream);
+/* The same for up to DSC_SMALLK_MAX heads in ONE launch (the first layers of the per-attribute encoders, denoise_net.py:513-524:
+ * every head reads its own column slice of the scene tensor and writes its own [m][n] block); items: HOST array.  Bit-identical to
+ * `count` single launches. */
+#define DSC_SMALLK_MAX 4
+typedef struct dsc_smallk_item { const float* x; int64_t ldx; int32_t k_in; const float* w; int64_t ldw; const float* bias;
+                                 float* y; int64_t ldy; } dsc_smallk_item;
+int dsc_linear_smallk_grouped_f32(const dsc_smallk_item* items, int32_t count, int32_t m, int32_t n, int32_t act_out,
+                                  dsc_stream_t stream);
+/* dst[r][dst_col + c] = src[r][src_col + c] for c < width, over up to DSC_SMALLK_MAX column spans (HOST array): the padded outputs of
+ * the stacked decoder output heads -> their columns of the (M, C) scene tensor. */
+typedef struct dsc_col_span { int32_t src_col, dst_col, width; } dsc_col_span;
+int dsc_gather_columns_f32(float* dst, int64_t ldd, const float* src, int64_t lds, int32_t rows, const dsc_col_span* spans,
+                           int32_t count, dsc_stream_t stream);
 
 /* WeightStandardizedConv2d.forward weight path (denoise_net.py:84-89):
  *   out[o][:] = (w[o][:] - mean_o) * rsqrt(var_o + eps), biased variance over the row.

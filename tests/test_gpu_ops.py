@@ -365,3 +365,25 @@ def test_gemm_with_layernorm_epilogue(m, k, res):
     var = o.var(1, unbiased=False, keepdim=True)
     ref = (o - mu) * torch.rsqrt(var + 1e-5) * g.double() + (r.double() if res else 0)
     assert float((y.double() - ref).abs().max() / ref.abs().max()) < 5e-6
+
+
+def test_grouped_smallk_and_column_gather_match_single_launches():
+    """Round 4 (sampling tail): the first layers of the three per-attribute encoders in ONE launch, and the gather that moves the padded
+    outputs of the stacked decoder heads into the (M, C) scene tensor -- bit-identical to the single launches / to a slice copy."""
+    from diffuscene_amd import ops
+    d = dev()
+    M, D = 20480 + 7, 512
+    x = (torch.rand(M, 65, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(d)
+    heads = [(8, 25), (0, 8), (33, 32)]                                     # (first column, width) of class / bbox / objfeat
+    ws = [(torch.rand(D, k, 1, generator=torch.Generator().manual_seed(2 + k)) - 0.5).to(d) for _, k in heads]
+    bs = [(torch.rand(D, generator=torch.Generator().manual_seed(9 + k)) - 0.5).to(d) for _, k in heads]
+    wide = torch.full((M, 3 * D), float("nan"), device=d)
+    ops.linear_smallk_grouped([x[:, c0:c0 + k] for c0, k in heads], ws, bs, [wide[:, i * D:(i + 1) * D] for i in range(3)], act_out=1)
+    for i, (c0, k) in enumerate(heads):
+        single = ops.linear_smallk(x[:, c0:c0 + k], ws[i], bs[i], act_out=1)
+        assert torch.equal(wide[:, i * D:(i + 1) * D], single), i
+    src = torch.rand(M, 96, device=d)
+    dst = torch.full((M, 65), float("nan"), device=d)
+    ops.gather_columns(dst, src, [(0, 0, 8), (32, 8, 25), (64, 33, 32)])
+    want = torch.cat([src[:, 0:8], src[:, 32:57], src[:, 64:96]], dim=1)
+    assert torch.equal(dst, want)
