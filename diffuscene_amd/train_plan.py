@@ -125,6 +125,11 @@ class HipBackend:
         self._planes = {}
         self._planes_new = []
         self.plane_bytes = 0
+        # Transposed weight copies (operands of the input-gradient GEMMs): the plan registers buffer -> source, and the planes of such
+        # a buffer are split STRAIGHT from the source with the transpose folded in (dsc_split_bf16x3_f32, transpose = 1).  The f32
+        # transpose itself is only launched for buffers some launch reads as f32 (`f32_reads`: products on the exact-f32 kernel)
+        self.transposed_of = {}                  # data_ptr of a dense [K][n] buffer -> source weight [n][K]
+        self.f32_reads = set()                   # storage pointers of weight operands read WITHOUT planes
 
     def planes_of(self, w, rows):
         """bf16 planes of weight operand ``w`` ([n][K], rows contiguous) for a product with ``rows`` activation rows, or None."""
@@ -136,7 +141,12 @@ class HipBackend:
         if ent is None:
             planes = torch.empty((3,) + tuple(w.shape), device=self.device, dtype=torch.int16)
             self.plane_bytes += planes.numel() * 2
-            ent = self._planes[key] = (w, planes)
+            src = self.transposed_of.get(w.data_ptr())
+            if src is not None and (not w.is_contiguous() or tuple(src.shape) != (w.shape[1], w.shape[0])):
+                src = None                       # a column slice / padded view of the transposed buffer: split the buffer itself
+            if src is None:
+                self.f32_reads.add(w.untyped_storage().data_ptr())       # the split launch reads this buffer as f32
+            ent = self._planes[key] = (w, planes, src)
             self._planes_new.append(ent)
         return ent[1]
 
@@ -149,7 +159,12 @@ class HipBackend:
         for i in range(0, len(ents), self.lib.WS_MAX):
             part = ents[i:i + self.lib.WS_MAX]
             arr = (self.lib.SplitItem * len(part))()
-            for j, (w, planes) in enumerate(part):
+            for j, (w, planes, src) in enumerate(part):
+                if src is not None:              # planes of w = src^T, read from the source: the f32 copy w is never needed for this
+                    ptr, ldw = ops._mat(src, "w")
+                    arr[j].w, arr[j].ldw, arr[j].rows, arr[j].cols, arr[j].planes, arr[j].transpose = (
+                        ptr, ldw, src.shape[0], src.shape[1], planes.data_ptr(), 1)
+                    continue
                 ptr, ldw = ops._mat(w, "w")
                 arr[j].w, arr[j].ldw, arr[j].rows, arr[j].cols, arr[j].planes, arr[j].transpose = (
                     ptr, ldw, w.shape[0], w.shape[1], planes.data_ptr(), 0)
@@ -210,11 +225,14 @@ class HipBackend:
                 floats = splits * m * out.shape[1]
                 g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
                 self.keep.append((g, a, w, out, bias, residual))
+                self.f32_reads.add(w.untyped_storage().data_ptr())
                 return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
         pl = self.planes_of(w, m) if ops.gemm_would_use_split(g) else None          # planes only for launches that will use them
         if pl is not None:
             g.w_planes = pl.data_ptr()
+        else:
+            self.f32_reads.add(w.untyped_storage().data_ptr())
         return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl))
 
     def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):
@@ -224,6 +242,8 @@ class HipBackend:
         pl = self.planes_of(w, a.shape[0]) if ops.gemm_would_use_split(g, gn=True) else None
         if pl is not None:
             g.w_planes = pl.data_ptr()
+        else:
+            self.f32_reads.add(w.untyped_storage().data_ptr())
         return self._call("dsc_gemm_gn_silu_f32", C.byref(g), keep=(g, a, w, out, bias, gamma, beta, a2, ss, residual, preact, pl))
 
     def smallk(self, x, w, bias, out, act_out=ACT_NONE):
@@ -758,6 +778,8 @@ class TrainPlan:
         if npad is None or npad == n:
             buf = self.new(K, n)
             self._transposes.append((w2d, buf))
+            if hasattr(self.be, "transposed_of"):
+                self.be.transposed_of[buf.data_ptr()] = w2d
             return buf
         buf = self.zeros(K, npad)
         self._transposes.append((w2d, buf[:, :n]))
@@ -1024,6 +1046,8 @@ class TrainPlan:
         self._fwd_split_at = len(self.fwd)            # the forward list's weight-plane splits go here (standardised weights final)
         for m in ws_mods:
             self._transposes.append((self.ws_std[id(m)], self.ws_t[id(m)]))
+            if hasattr(be, "transposed_of"):
+                be.transposed_of[self.ws_t[id(m)].data_ptr()] = self.ws_std[id(m)]
         # ---- conditioning
         t_blocks = [rb for rb, kind in blocks if kind == "t"]
         c_blocks = [rb for rb, kind in blocks if kind == "c" and rb.mlp is not None]
@@ -1218,7 +1242,20 @@ class TrainPlan:
         body = self.bwd
         self.bwd = []
         self._cur = self.bwd
-        self.emit(be.transpose_many(self._transposes))
+        tr = self._transposes
+        if hasattr(be, "f32_reads"):
+            # a transposed f32 copy is launched only when some product reads it as f32 (a launch on the exact-f32 kernel, or a plane
+            # split of a slice of it); where every consumer takes bf16 planes, the planes come straight from the source weight with
+            # the transpose folded into the split (HipBackend.split_steps) and the copy is never made.  The buffers skipped here are
+            # poisoned once, so that a read nobody planned for shows up as NaN gradients instead of stale values
+            keep = [(w, o) for w, o in tr if o.untyped_storage().data_ptr() in be.f32_reads]
+            for w, o in tr:
+                if o.untyped_storage().data_ptr() not in be.f32_reads:
+                    o.fill_(float("nan"))
+            self.n_transposes_skipped = len(tr) - len(keep)
+            tr = keep
+        if tr:
+            self.emit(be.transpose_many(tr))
         if hasattr(be, "split_steps"):                # planes of the transposed weights (operands of the input-gradient GEMMs)
             self.emit(be.split_steps())
         shift = len(self.bwd)

@@ -76,6 +76,8 @@ def test_text_training_plan_builds_on_the_host_with_short_slice_counts(tmp_path,
     assert len(plan.fwd) > 150 and len(plan.bwd) > 250
     assert chosen and all(c == (135, (1, 1536)) for c in chosen), chosen      # (the block map asks the same rule for the reference length)
     assert plan.n_adds == 8              # only the 8 skip-connection adds are left (round 3: 8 + one per LayerNorm input)
+    # text (M = 1536) multiplies on the exact-f32 kernel: every transposed weight copy is read as f32, none may be skipped
+    assert plan.n_transposes_skipped == 0
 
 
 def test_block_map_puts_a_layers_tiles_on_one_xcd_and_covers_every_tile_once():
