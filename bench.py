@@ -532,7 +532,7 @@ def ddp_selftest(args, device):
         if not dist.is_initialized():
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=device)
         os.environ["DSC_DDP_FORCE"] = "1"
-        for flush in ("block", "end"):
+        for flush in ("block", "end", "single"):
             os.environ["DSC_DDP_FLUSH"] = flush
             model, _ = build_model(spec, device)
             ms, tr = step_ms(spec, model)

@@ -89,10 +89,16 @@ class PlanRunner:
         # end of the backward); round 3, when the single-GPU schedule itself had 3 launches, measured on one GPU (bench.py
         # --ddp-selftest, profiles/r03_bench_ddp_selftest.json): +1.2 % per step at B=256, +4.3 % at B=32.  "block" flushes the weight
         # gradients every few ResnetBlocks so that buckets leave earlier (7 segments: +4.3 % / +9.9 %)
-        per_block = distributed and os.environ.get("DSC_DDP_FLUSH", "end") == "block"
+        flush = os.environ.get("DSC_DDP_FLUSH", "end")
+        if flush not in ("end", "block", "single"):
+            raise ValueError("DSC_DDP_FLUSH=%r: must be 'end' (default), 'block' or 'single'" % flush)
+        per_block = distributed and flush == "block"
+        # "single": the single-GPU schedule unchanged (ONE grouped launch at the end of the backward, no token slices): the cheapest
+        # compute (+0 %) and NO overlap -- every bucket finishes with the last launch; the right choice when the all-reduce is fast
+        thirds = distributed and flush == "end"
         from ._lib import split_enabled
         arith = split_enabled() if PlanRunner.backend_factory is None else None      # plans bake the arithmetic in (planes, TN form)
-        key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block, arith)
+        key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block, thirds, arith)
         ent = self.plans.pop(key, None)
         if ent is None:
             model = self.model
@@ -107,7 +113,7 @@ class PlanRunner:
             plan = TrainPlan(model.diffusion.model, self.flat, model.diffusion.diffusion, B, N, ctx_mode, ctx_dim, L,
                              text_dim, backend, per_block_grads=per_block, ctx_param=ctx_param,
                              grad_scale=1.0 / (B * ws),
-                             tn_flush_floats=self.flat.numel // 3 if (distributed and not per_block) else None)
+                             tn_flush_floats=self.flat.numel // 3 if thirds else None)
             ent = {"plan": plan, "graph": None, "reducer": None, "warm": 0}
             if distributed:
                 from .ddp import FlatGradientReducer
