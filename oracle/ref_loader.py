@@ -8,6 +8,7 @@ unused tkinter imports of denoise_net.py:6-7 are stubbed.
 ``/root/reference`` does not exist on the GPU box; callers must guard with
 ``reference_available()``.
 """
+import importlib.machinery
 import importlib.util
 import os
 import sys
@@ -170,6 +171,7 @@ def prepare_reference_script_imports():
             except ImportError:
                 m = types.ModuleType(name)
                 m.__path__ = []
+                m.__spec__ = importlib.machinery.ModuleSpec(name, None)      # importlib.util.find_spec(name) must not choke on the stub
                 m.__getattr__ = _stub_getattr
                 sys.modules[name] = m
                 made.append(name)

@@ -26,8 +26,21 @@ from oracle.ref_loader import prepare_reference_script_imports, reference_availa
 pytestmark = pytest.mark.skipif(not reference_available(), reason="the reference tree is only present in the build container")
 
 
-def test_real_train_diffusion_script_drives_the_package(tmp_path, golden_dir, monkeypatch):
-    prepare_reference_script_imports()
+@pytest.fixture
+def script_imports():
+    """Stubs and aliases only live for this test: later tests (transformers probing for wandb, the reference loaders of the golden
+    generators) must see the interpreter as they would without it."""
+    before = set(sys.modules)
+    path = list(sys.path)
+    made = prepare_reference_script_imports()
+    yield made
+    for name in set(sys.modules) - before:
+        if name.split(".")[0] in {m.split(".")[0] for m in made} or name.startswith(("scene_synthesis", "train_diffusion", "training_utils")):
+            sys.modules.pop(name, None)
+    sys.path[:] = path
+
+
+def test_real_train_diffusion_script_drives_the_package(tmp_path, golden_dir, monkeypatch, script_imports):
     import scene_synthesis.networks as nets
     import diffuscene_amd.networks as ours
     assert nets is ours
