@@ -235,6 +235,24 @@ class HipBackend:
             self.f32_reads.add(w.untyped_storage().data_ptr())
         return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl))
 
+    def gemm_long_k(self, a, w, out, residual=None):
+        """out = a @ w^T (+ residual) for a LONG reduction (K > 4096) with few output tiles: one dsc_gemm_splitk_f32 launch with the most
+        slabs (<= 64) that keep a slab >= 256 terms -- or None when the shape does not fit that entry point (the caller chunks)."""
+        from . import ops
+        m, K = a.shape
+        n = out.shape[1]
+        if (m * n) % 4 or K % 32:
+            return None
+        splits = next((s for s in range(64, 1, -1) if K % (32 * s) == 0 and K // s >= 256), 0)
+        if not splits:
+            return None
+        fn = self.lib.fn("dsc_gemm_splitk_f32")
+        g = ops.make_gemm_args(a, w, out, None, None, residual, ACT_NONE, ACT_NONE)
+        self.keep.append((g, a, w, out, residual))
+        self.f32_reads.add(w.untyped_storage().data_ptr())
+        floats = splits * m * n
+        return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
+
     def gemm_gn(self, a, w, out, bias, gamma, beta, n_tok, a2=None, ss=None, ss_mode=SS_NONE, residual=None, preact=None):
         from . import ops
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5, tokens_per_scene=n_tok,
@@ -727,9 +745,17 @@ class TrainPlan:
 
     def _gemm_acc(self, dy, wt, dst, acc):
         n = dy.shape[1]
+        if n > 4096 and hasattr(self.be, "gemm_long_k"):
+            # long reductions (the packed 19 x 1024 time-MLP outputs, K = 19456; the 9 x 1024 context-MLP outputs): ONE split-K launch
+            # whose slabs are <= 512 terms long (blocked sum: the fp32 error of short chains, as the chunked form below) instead of ten
+            # chunk launches of 25 us each (round 4)
+            step = self.be.gemm_long_k(dy, wt, dst, dst if acc else None)
+            if step is not None:
+                self.emit(step)
+                return
         if n > 4096:
-            # long reductions (the packed 19x1024 time-MLP outputs): accumulate in chunks of 2048 so that the fp32 error
-            # stays that of a blocked sum instead of one 19456-term sequential chain
+            # long reductions: accumulate in chunks of 2048 so that the fp32 error stays that of a blocked sum instead of one
+            # 19456-term sequential chain
             for c0 in range(0, n, 2048):
                 c1 = min(c0 + 2048, n)
                 self.emit(self.be.gemm(dy[:, c0:c1], wt[:, c0:c1], dst, residual=dst if (acc or c0 > 0) else None))
