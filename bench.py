@@ -408,10 +408,13 @@ def cpu_baseline(spec, mode):
         torch.set_num_threads(th)
         for f in legs:
             f(q)
-        t1 = time.perf_counter()
-        for f in legs:
-            f(q)
-        d = time.perf_counter() - t1
+        d = None
+        for _ in range(2):                          # best of two: one stray slow run must not pick the thread count
+            t1 = time.perf_counter()
+            for f in legs:
+                f(q)
+            e = time.perf_counter() - t1
+            d = e if d is None else min(d, e)
         log("cpu_baseline: %d threads -> %.3f s per %s step on %d scenes" % (th, d, mode, q.stop))
         if best is None or d < best[1]:
             best = (th, d)
@@ -594,7 +597,7 @@ def main():
     if os.environ.get("DSC_BENCH_DRYRUN"):          # launcher plumbing only (CPU test): what each rank would run
         print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "world": ws, "gpus": args.gpus,
                           "config": args.config, "scaling": args.scaling, "master": os.environ.get("MASTER_ADDR"),
-                          "ddp_flush": os.environ.get("DSC_DDP_FLUSH", "end"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                          "ddp_flush": os.environ.get("DSC_DDP_FLUSH", "block"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                           "batch_per_rank": (CONFIGS[args.config]["batch"] // ws) if args.scaling == "strong"
                           else CONFIGS[args.config]["batch"]}), flush=True)
         if ws != args.gpus:

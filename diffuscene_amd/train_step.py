@@ -84,17 +84,17 @@ class PlanRunner:
         from .train_plan import HipBackend, TrainPlan
         ws = self.world()
         distributed = self.distributed()
-        # data parallel: "end" (default) launches the pending weight-gradient group whenever it holds a third of G -- 3 grouped
-        # launches, 3+ graph segments, most buckets leave before the last segment (the single-GPU plan keeps ONE grouped launch at the
-        # end of the backward); round 3, when the single-GPU schedule itself had 3 launches, measured on one GPU (bench.py
-        # --ddp-selftest, profiles/r03_bench_ddp_selftest.json): +1.2 % per step at B=256, +4.3 % at B=32.  "block" flushes the weight
-        # gradients every few ResnetBlocks so that buckets leave earlier (7 segments: +4.3 % / +9.9 %)
-        flush = os.environ.get("DSC_DDP_FLUSH", "end")
+        # data parallel, DSC_DDP_FLUSH = when the grouped weight-gradient launches run (the single-GPU plan keeps ONE at the end of the
+        # backward); measured on one GPU with a world-1 RCCL group (bench.py --ddp-selftest, profiles/r04_bench_ddp_selftest.json; B = 256 /
+        # B = 32 scenes per GPU, over the single-GPU graph step):
+        #   "block" (default)  a flush every few ResnetBlocks, 7 graph segments: buckets leave all through the backward   +5.2 % / +10.8 %
+        #   "end"              whenever a third of G is pending: 3 launches, two thirds of the exchange can overlap       +9.2 % /  +8.7 %
+        #   "single"           the single-GPU schedule unchanged: cheapest compute, NO overlap (every bucket finishes with
+        #                      the last launch); the right choice when the 311 MB all-reduce is faster than ~1 ms          +1.5 % /  +1.8 %
+        flush = os.environ.get("DSC_DDP_FLUSH", "block")
         if flush not in ("end", "block", "single"):
-            raise ValueError("DSC_DDP_FLUSH=%r: must be 'end' (default), 'block' or 'single'" % flush)
+            raise ValueError("DSC_DDP_FLUSH=%r: must be 'block' (default), 'end' or 'single'" % flush)
         per_block = distributed and flush == "block"
-        # "single": the single-GPU schedule unchanged (ONE grouped launch at the end of the backward, no token slices): the cheapest
-        # compute (+0 %) and NO overlap -- every bucket finishes with the last launch; the right choice when the all-reduce is fast
         thirds = distributed and flush == "end"
         from ._lib import split_enabled
         arith = split_enabled() if PlanRunner.backend_factory is None else None      # plans bake the arithmetic in (planes, TN form)
