@@ -66,6 +66,12 @@ def tn_token_slices(groups, tile_n, blocks_target):
     return max(1, min(32, m_ref // 256, -(-blocks_target // max(long_tiles, 1)))), m_ref
 
 
+def long_k_splits(K):
+    """Slabs of ONE split-K launch over a long reduction (dsc_gemm_splitk_f32: K % (32 * splits) == 0, splits <= 64): the most slabs that
+    keep a slab >= 256 terms -- short fp32 chains, one launch.  0 = the shape does not fit (the caller accumulates in chunks)."""
+    return next((s for s in range(64, 1, -1) if K % (32 * s) == 0 and K // s >= 256), 0)
+
+
 def tn_block_map(groups, n_xcd=8):
     """Block placement of one grouped weight-gradient launch on the split-bf16 kernel (256 x 128 tiles).
     groups: (m tokens, n, k) per group, in table order.  -> list of (group, tile of the group) per PHYSICAL block id, (-1, -1) = idle.
@@ -243,7 +249,7 @@ class HipBackend:
         n = out.shape[1]
         if (m * n) % 4 or K % 32:
             return None
-        splits = next((s for s in range(64, 1, -1) if K % (32 * s) == 0 and K // s >= 256), 0)
+        splits = long_k_splits(K)
         if not splits:
             return None
         fn = self.lib.fn("dsc_gemm_splitk_f32")

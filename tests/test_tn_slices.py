@@ -132,3 +132,20 @@ def test_block_map_small_launches():
     bm = tn_block_map([(64, 1024, 512), (1290, 32, 512)])            # 16 short tiles + 4 long: long first on XCD 0, short dealt around
     assert sorted(gt for gt in bm if gt[0] >= 0) == sorted([(0, t) for t in range(16)] + [(1, t) for t in range(4)])
     assert [bm[8 * i] for i in range(4)] == [(1, 0), (1, 1), (1, 2), (1, 3)]
+
+
+def test_long_k_split_choice_and_hazard_check():
+    """Two small host rules of the training plan: the slab count of the single split-K launch that replaced the chunked long-K input
+    gradients, and the column-exact hazard check that keeps one half of a skip-connection pair buffer from flushing GEMMs that read the
+    other half."""
+    import torch
+    from diffuscene_amd.train_plan import TrainPlan, long_k_splits
+    assert long_k_splits(19456) == 38 and 19456 // 38 == 512            # packed time-MLP outputs: 38 slabs of 512 terms
+    assert long_k_splits(9216) == 36 and 9216 // 36 == 256               # context-MLP outputs
+    assert long_k_splits(4128) == 3                                      # 129 * 32: only 3 and 43 divide it; 43 slabs would be 96 terms
+    assert long_k_splits(8224) == 0                                      # 257 * 32: prime factor, no admissible slab count -> chunked form
+    buf = torch.zeros(12, 1024)
+    left, right = buf[:, :512], buf[:, 512:]
+    assert not TrainPlan._may_overlap(left, right) and not TrainPlan._may_overlap(right, left)
+    assert TrainPlan._may_overlap(left, buf[:, 256:768]) and TrainPlan._may_overlap(left, left)
+    assert TrainPlan._may_overlap(left, buf.view(-1)[:512].view(1, 512)[:, :])          # different row stride: assume the worst
