@@ -79,8 +79,8 @@ def tn_block_map(groups, n_xcd=8):
     Consecutive workgroup ids are dealt round-robin over the XCDs (id % 8), each with its own L2, and the tiles of one layer share its
     operand strips -- so every "long" group (one that carries the launch: at least half the reference token length of tn_token_slices)
     goes WHOLE to one XCD, longest first, always to the XCD with the least work so far; the tiles of the remaining groups (the packed
-    time-MLP gradient: 1216 tiles over 256 tokens; tiny conditioning layers) are dealt one by one to the emptiest XCD, behind the
-    long ones.  Every XCD then walks its list in order: physical block b = 8 * position + xcd."""
+    time-MLP gradient: 1216 tiles over 256 tokens; tiny conditioning layers) are dealt one by one to the SHORTEST list (their token work is negligible, padding
+    blocks are not), behind the long ones.  Every XCD then walks its list in order: physical block b = 8 * position + xcd."""
     def tiles(n, k):
         return ((n + 255) // 256) * ((k + 127) // 128)
     _, m_ref = tn_token_slices(groups, 256, 768)
@@ -97,12 +97,11 @@ def tn_block_map(groups, n_xcd=8):
             work[x] += nt * m
         else:
             short.append(gi)
-    for gi in short:
+    for gi in short:                                     # (by list LENGTH: their token work is negligible, idle padding is not)
         m, n, k = groups[gi]
         for t in range(tiles(n, k)):
-            x = min(range(n_xcd), key=lambda j: (work[j], j))
+            x = min(range(n_xcd), key=lambda j: (len(lists[j]), j))
             lists[x].append((gi, t))
-            work[x] += m
     depth = max(len(l) for l in lists)
     out = []
     for pos in range(depth):
