@@ -66,16 +66,28 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_split_pair_kernel(const 
 
 }  // namespace dsc_split
 
-// both layers must have the shape of the headline launch: n = 512 (two 256-wide column blocks), scenes of 65..80 tokens, 8-wave tile
+// the tile the product's dispatcher would take for this launch shape: 65..80 tokens per scene and >= 192 eight-wave blocks -> <2,4,5>
+// (headline, B = 256); fewer -> the four-wave <2,2,5> (B = 128: complete / arrange); 17..32 tokens -> <4,2,2> (bedroom21)
+template <int WM, int WN, int RB>
+static int launch_pair(const dsc_gemm_args* a1, const dsc_gemm_args* a2, unsigned* flags, unsigned* err, int fence, hipStream_t s) {
+    const int N = a1->tokens_per_scene;
+    const int scenes = (a1->m + N - 1) / N;
+    const unsigned grid = (unsigned)(((scenes + WM - 1) / WM) * (a1->n / (64 * WN)));
+    if (grid > 256) return DSC_ERANGE;                  // every block must be resident: one block per CU
+    hipLaunchKernelGGL((dsc_split::gemm_split_pair_kernel<WM, WN, RB>), dim3(grid), dim3(64 * WM * WN), 0, s, *a1, *a2, N, flags, err, fence);
+    return (int)hipGetLastError();
+}
+
 extern "C" int probe_gn_pair(const dsc_gemm_args* a1, const dsc_gemm_args* a2, unsigned* flags, unsigned* err, int fence, void* stream) {
-    using namespace dsc_split;
     if (!a1 || !a2 || !flags || !err || a1->m != a2->m || a1->n != a2->n || a1->n % 256 || !a1->w_planes || !a2->w_planes) return DSC_EINVAL;
     const int N = a1->tokens_per_scene;
-    if (N <= 64 || N > 80 || a2->tokens_per_scene != N || a1->batch != 1 || a2->batch != 1) return DSC_EINVAL;
+    if (a2->tokens_per_scene != N || a1->batch != 1 || a2->batch != 1) return DSC_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const int scenes = (a1->m + N - 1) / N;
-    const unsigned grid = (unsigned)(((scenes + 1) / 2) * (a1->n / 256));
-    if (grid > 256) return DSC_ERANGE;                  // every block must be resident: one 8-wave block per CU
-    hipLaunchKernelGGL((gemm_split_pair_kernel<2, 4, 5>), dim3(grid), dim3(512), 0, static_cast<hipStream_t>(stream), *a1, *a2, N, flags, err,
-                       fence);
-    return (int)hipGetLastError();
+    if (N > 64 && N <= 80) {
+        if (((scenes + 1) / 2) * (a1->n / 256) >= 192) return launch_pair<2, 4, 5>(a1, a2, flags, err, fence, s);
+        return launch_pair<2, 2, 5>(a1, a2, flags, err, fence, s);
+    }
+    if (N > 16 && N <= 32) return launch_pair<4, 2, 2>(a1, a2, flags, err, fence, s);
+    return DSC_EINVAL;
 }

@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--objects", type=int, default=80, help="tokens per scene: 80 (living; B=256 eight-wave tile, B=128 four-wave tile) or 21 (bedroom)")
     ap.add_argument("--blocks", type=int, default=8, help="ResnetBlocks per captured chain")
     ap.add_argument("--rounds", type=int, default=9)
     a = ap.parse_args()
@@ -45,7 +46,7 @@ def main():
     probe.probe_gn_pair.restype = C.c_int
     probe.probe_gn_pair.argtypes = [C.POINTER(_lib.GemmArgs), C.POINTER(_lib.GemmArgs), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     dev = torch.device("cuda:0")
-    B, N, D = a.batch, 80, 512
+    B, N, D = a.batch, a.objects, 512
     M = B * N
     g = torch.Generator().manual_seed(0)
 
