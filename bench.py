@@ -488,6 +488,25 @@ def side_line(name, device, arith=None, steps=6, warm=3):
             _lib.set_gemm_arithmetic(prev)
 
 
+def side_line_child(what, timeout=600):
+    """side_line(CONFIG[:ARITH]) in a CHILD process (`python bench.py --side-line ...`): a side line must never cost the headline line --
+    an exception, a hang or a GPU fault there ends the child and is recorded as {"error": ...}; the parent still prints its line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--side-line", what]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %d s" % timeout}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode == 0 and lines:
+        try:
+            return json.loads(lines[-1])
+        except ValueError:
+            pass
+    tail = " | ".join((r.stderr or "").strip().splitlines()[-3:])
+    return {"error": "child exit code %d: %s" % (r.returncode, tail[-400:])}
+
+
 # ------------------------------------------------------------------------------------------ launcher
 def _free_port():
     with socket.socket() as s:
@@ -583,6 +602,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` / `exact_f32` blocks the default single-GPU run appends after the headline line's "
                          "timed region (the four other BASELINE configs and the metric config on the exact-f32 kernels, 6+6 steps each)")
+    ap.add_argument("--side-line", default=None, metavar="CONFIG[:ARITH]",
+                    help="(internal) print the compact side line of one configuration and exit: the default run launches one child "
+                         "process per side line, so that nothing that happens there can cost the headline line")
     ap.add_argument("--ddp-selftest", action="store_true",
                     help="one GPU: time the DATA-PARALLEL form of the training step (world-1 RCCL group, reducer forced on: bucket "
                          "schedule, hipGraph segments, 8 in-place all-reduces) next to the single-GPU graph step, at the config's "
@@ -618,6 +640,12 @@ def main():
         if ws != 1:
             raise SystemExit("bench.py: --ddp-selftest is a single-GPU run")
         return ddp_selftest(args, device)
+    if args.side_line:
+        if ws != 1:
+            raise SystemExit("bench.py: --side-line is a single-GPU run")
+        name, _, arith = args.side_line.partition(":")
+        print(json.dumps(side_line(name, device, arith=arith or None)), flush=True)
+        return
 
     spec = dict(CONFIGS[args.config])
     if args.batch:
@@ -739,16 +767,10 @@ def main():
             torch.cuda.empty_cache()
             out["other_configs"] = {}
             for name in ("bedroom21", "text", "complete", "arrange"):
-                try:
-                    out["other_configs"][name] = side_line(name, device)
-                except Exception as e:                     # noqa: BLE001 -- a side line must never cost the headline line
-                    out["other_configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["other_configs"][name] = side_line_child(name)
                 log("other_configs: %s done" % name)
             if _lib.split_enabled():
-                try:
-                    out["exact_f32"] = side_line("living80", device, arith="f32")
-                except Exception as e:                     # noqa: BLE001
-                    out["exact_f32"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["exact_f32"] = side_line_child("living80:f32")
                 log("exact_f32 done")
         print(json.dumps(out), flush=True)
     if ws > 1:
