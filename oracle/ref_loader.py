@@ -153,7 +153,10 @@ def _stub_getattr(n):
 # the cached-dataset training path the script takes
 _SCRIPT_STUBS = ("trimesh", "simple_3dviz", "simple_3dviz.renderables", "simple_3dviz.renderables.textured_mesh", "simple_3dviz.behaviours",
                  "simple_3dviz.behaviours.keyboard", "simple_3dviz.behaviours.misc", "torchtext", "num2words", "nltk", "nltk.tokenize",
-                 "nltk.corpus", "wandb")
+                 "nltk.corpus", "wandb",
+                 # scripts/generate_diffusion.py + scripts/utils.py + scene_synthesis/utils.py: rendering / mesh IO (out of scope)
+                 "simple_3dviz.utils", "simple_3dviz.behaviours.movements", "simple_3dviz.behaviours.trajectory", "simple_3dviz.behaviours.io",
+                 "pyrr", "open3d", "pyvista", "seaborn", "turtle")
 
 
 def prepare_reference_script_imports():

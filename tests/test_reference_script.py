@@ -101,3 +101,84 @@ def test_real_train_diffusion_script_drives_the_package(tmp_path, golden_dir, mo
     calls["train"].clear()
     train_diffusion.main([str(cfg_path), str(out), "--experiment_tag", "exp", "--seed", "3"])
     assert calls["train"] == []
+
+
+def test_real_generate_diffusion_script_drives_the_package(tmp_path, golden_dir, monkeypatch, script_imports):
+    """/root/reference/scripts/generate_diffusion.py, unchanged: argument parsing -> the reference's own test-split dataset ->
+    ``build_network(feature_size, n_classes, config, weight_file, device)`` loading a checkpoint OUR model wrote -> ``network.eval()`` ->
+    ``network.generate_layout(room_mask=, num_points=, point_dim=, text=, device=, clip_denoised=, batch_seeds=)`` (our wrapper's real
+    method: only the reverse loop under it, ``sample``, is a recorder -- there is no GPU here) -> OUR post-filter dict through the REFERENCE's
+    ``dataset.post_process`` -> the tensors the script hands to shape retrieval.  Rendering and mesh export (out of scope) are
+    stubs; retrieval itself is tests/test_gpu_retrieval.py."""
+    import scene_synthesis.networks as nets
+    import diffuscene_amd.networks as ours
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    assert nets is ours
+    root = str(tmp_path / "cached")
+    ids = DR.write_synth_cached_dataset(root, 20, seed=1, max_length=12)
+    with open(tmp_path / "splits.csv", "w") as f:
+        for i, sid in enumerate(ids):
+            f.write("%s,%s\n" % (sid, "test" if i % 4 == 3 else "train"))
+    cfgs = json.load(open(os.path.join(golden_dir, "reference_configs.json")))
+    config = copy.deepcopy(cfgs["uncond/diffusion_bedrooms_instancond_lat32_v.yaml"])
+    config["data"].update(dataset_directory=root, annotation_file=str(tmp_path / "splits.csv"), filter_fn="no_filtering")
+    config["network"]["diffusion_kwargs"]["train_stats_file"] = os.path.join(root, "dataset_stats.txt")
+    nc = DR.N_OBJECT_TYPES + 1
+    N, C = config["network"]["sample_num_points"], config["network"]["point_dim"]
+    assert (N, C) == (12, 8 + nc + 32)
+    cfg_path = tmp_path / "config.yaml"
+    cfg_path.write_text(yaml.safe_dump(config))
+    # a checkpoint written by OUR model, as scripts/train_diffusion.py saves it (state_dict through torch.save)
+    torch.manual_seed(5)
+    trained, _, _ = ours.build_network(None, nc, config, None, device="cpu")
+    weights = tmp_path / "model_00010"
+    torch.save(trained.state_dict(), str(weights))
+
+    import generate_diffusion
+    calls = {"sample": [], "retrieval": [], "onlysize": []}
+    futures = ["the pickled 3D-FUTURE models"]
+    monkeypatch.setattr(generate_diffusion.ThreedFutureDataset, "from_pickled_dataset", staticmethod(lambda path: futures))
+    monkeypatch.setattr(generate_diffusion, "floor_plan_from_scene",
+                        lambda scene, textures, no_texture=False: (["floor"], ["floor mesh"], torch.zeros(1, 1, 64, 64)))
+
+    def rec_sample(self, room_mask, num_points, point_dim, batch_size=1, text=None, partial_boxes=None, input_boxes=None, ret_traj=False,
+                   ddim=False, clip_denoised=False, freq=40, batch_seeds=None):
+        # what the script's call reaches the reverse loop with
+        assert isinstance(self, DiffusionSceneLayout_DDPM) and not self.training
+        assert tuple(room_mask.shape) == (1, 1, 64, 64) and (num_points, point_dim, batch_size) == (N, C, 1)
+        assert text is None and partial_boxes is None and input_boxes is None and clip_denoised is True and not ret_traj
+        assert torch.equal(batch_seeds, torch.arange(len(calls["sample"]), len(calls["sample"]) + 1))
+        sd = self.state_dict()
+        assert all(torch.equal(sd[k], v) for k, v in trained.state_dict().items())           # the checkpoint really was loaded
+        g = torch.Generator().manual_seed(len(calls["sample"]))
+        x = torch.rand(1, N, C, generator=g) * 2 - 1
+        x[0, 5:, 8 + nc - 1] = 1.0                     # slots 5.. are 'empty' (logit >= 0): the post-filter drops them
+        x[0, :5, 8 + nc - 1] = -1.0
+        calls["sample"].append(x.clone())
+        return x
+    monkeypatch.setattr(DiffusionSceneLayout_DDPM, "sample", rec_sample)
+
+    def rec_retrieve(bbox_params_t, objects_dataset, classes, diffusion=False, no_texture=False, query_objfeats=None):
+        assert objects_dataset is futures and diffusion and no_texture
+        assert tuple(bbox_params_t.shape) == (1, 5, (nc - 1) + 3 + 3 + 1) and len(classes) == nc + 1     # 21 types + 'start' + 'end'
+        assert query_objfeats is None or tuple(query_objfeats.shape) == (1, 5, 32)
+        (calls["retrieval"] if query_objfeats is not None else calls["onlysize"]).append((bbox_params_t.copy(), query_objfeats))
+        return [], [], []
+    monkeypatch.setattr(generate_diffusion, "get_textured_objects_based_on_objfeats", rec_retrieve)
+    monkeypatch.setattr(generate_diffusion, "get_textured_objects", rec_retrieve)
+
+    out = tmp_path / "generated"
+    generate_diffusion.main([str(cfg_path), str(out), str(tmp_path / "futures.pkl"), "--weight_file", str(weights), "--n_sequences", "2",
+                             "--clip_denoised", "--retrive_objfeats", "--no_texture", "--fix_order", "--without_screen"])
+    assert len(calls["sample"]) == 2 and len(calls["retrieval"]) == 2 and len(calls["onlysize"]) == 2
+    # the numbers the script hands to retrieval are the reference's post_process of OUR post-filter's dict: classes as they are,
+    # translations / sizes descaled by the dataset bounds, the angle back from (cos, sin), the latent codes descaled
+    import numpy as np
+    stats = json.load(open(os.path.join(root, "dataset_stats.txt")))
+    for x, (boxes, feats) in zip(calls["sample"], calls["retrieval"]):
+        kept = x[0, :5].numpy()
+        assert np.array_equal(boxes[0, :, :nc - 1], kept[:, 8:8 + nc - 1])
+        lo, hi = np.array(stats["bounds_translations"][:3], np.float32), np.array(stats["bounds_translations"][3:], np.float32)
+        assert np.allclose(boxes[0, :, nc - 1:nc + 2], (kept[:, 0:3] + 1) / 2 * (hi - lo) + lo, rtol=1e-6, atol=1e-6)
+        assert np.allclose(boxes[0, :, -1], np.arctan2(kept[:, 7], kept[:, 6]), rtol=1e-6, atol=1e-6)
+        assert feats.shape == (1, 5, 32)
