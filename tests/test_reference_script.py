@@ -182,3 +182,94 @@ def test_real_generate_diffusion_script_drives_the_package(tmp_path, golden_dir,
         assert np.allclose(boxes[0, :, nc - 1:nc + 2], (kept[:, 0:3] + 1) / 2 * (hi - lo) + lo, rtol=1e-6, atol=1e-6)
         assert np.allclose(boxes[0, :, -1], np.arctan2(kept[:, 7], kept[:, 6]), rtol=1e-6, atol=1e-6)
         assert feats.shape == (1, 5, 32)
+
+
+@pytest.mark.parametrize("mode", ["complete", "arrange"])
+def test_real_completion_rearrange_script_drives_the_package(mode, tmp_path, golden_dir, monkeypatch, script_imports):
+    """/root/reference/scripts/completion_rearrange.py, unchanged, in both of its modes: the reference's test-split dataset -> ``build_network``
+    with a checkpoint our model wrote -> (re-arrangement) ``network.delete_empty_boxes`` on the noisy input dict -> ``network.complete_scene(
+    room_mask=, num_points=, point_dim=, partial_boxes=, device=, clip_denoised=, batch_seeds=)`` / ``network.arrange_scene(..., input_boxes=, ...)``
+    -- our wrapper's real methods over a recorder ``sample`` that checks the [translation | size | angle | class | objfeat] rows the script
+    assembled from the dataset sample -> the reference's ``post_process`` of our dict -> the renderer's inputs.  Rendering is stubbed."""
+    import numpy as np
+    import diffuscene_amd.networks as ours
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    root = str(tmp_path / "cached")
+    ids = DR.write_synth_cached_dataset(root, 20, seed=2, max_length=12)
+    with open(tmp_path / "splits.csv", "w") as f:
+        for i, sid in enumerate(ids):
+            f.write("%s,%s\n" % (sid, "test" if i % 4 == 3 else "train"))
+    cfgs = json.load(open(os.path.join(golden_dir, "reference_configs.json")))
+    name = {"complete": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml",
+            "arrange": "rearrange/diffusion_bedrooms_instancond_lat32_v_rearrange.yaml"}[mode]
+    config = copy.deepcopy(cfgs[name])
+    config["data"].update(dataset_directory=root, annotation_file=str(tmp_path / "splits.csv"), filter_fn="no_filtering")
+    config["network"]["diffusion_kwargs"]["train_stats_file"] = os.path.join(root, "dataset_stats.txt")
+    config["validation"]["gen_gt"] = False
+    nc = DR.N_OBJECT_TYPES + 1
+    N, C = config["network"]["sample_num_points"], config["network"]["point_dim"]
+    assert N == 12 and bool(config["network"].get("room_arrange_condition", False)) == (mode == "arrange")
+    cfg_path = tmp_path / "config.yaml"
+    cfg_path.write_text(yaml.safe_dump(config))
+    torch.manual_seed(6)
+    trained, _, _ = ours.build_network(None, nc, config, None, device="cpu")
+    weights = tmp_path / "model_00020"
+    torch.save(trained.state_dict(), str(weights))
+
+    import completion_rearrange as script
+    futures = ["the pickled 3D-FUTURE models"]
+    monkeypatch.setattr(script.ThreedFutureDataset, "from_pickled_dataset", staticmethod(lambda path: futures))
+    monkeypatch.setattr(script, "floor_plan_from_scene",
+                        lambda scene, textures, no_texture=False: (["floor"], ["floor mesh"], torch.zeros(1, 1, 64, 64)))
+    seen = {"sample": [], "folders": [], "final": []}
+    P = 3
+
+    def rec_sample(self, room_mask, num_points, point_dim, batch_size=1, text=None, partial_boxes=None, input_boxes=None, ret_traj=False,
+                   ddim=False, clip_denoised=False, freq=40, batch_seeds=None):
+        assert not self.training and (num_points, point_dim, batch_size) == (N, C, 1) and text is None and clip_denoised is True
+        given = partial_boxes if mode == "complete" else input_boxes
+        assert (partial_boxes is None) != (input_boxes is None) and given.dtype == torch.float32
+        assert tuple(given.shape) == ((1, P, 8 + nc + 32) if mode == "complete" else (1, N, 8 + nc + 32))
+        # the column layout the reverse loops expect: class scores (-1 / +1 from the dataset encoding) at 8 .. 8+nc, (cos, sin) at 6, 7
+        assert float(given[0, :, 8:8 + nc].abs().max()) == 1.0 and float(given[0, :, 8:8 + nc].abs().min()) == 1.0
+        if mode == "complete":
+            assert torch.allclose(given[0, :, 6] ** 2 + given[0, :, 7] ** 2, torch.ones(P), atol=1e-5)
+        seen["sample"].append(given.clone())
+        width = C if mode == "complete" else 8 + nc + 32            # arrange_samples re-assembles the full rows at t == 0
+        g = torch.Generator().manual_seed(7)
+        x = torch.rand(1, N, width, generator=g) * 2 - 1
+        x[0, :, 8 + nc - 1] = torch.tensor([-1.0] * 4 + [1.0] * (N - 4))
+        return x
+    monkeypatch.setattr(DiffusionSceneLayout_DDPM, "sample", rec_sample)
+
+    def rec_folder(args, folder, tag, dataset, objects_dataset, tr_floor, floor_plan, scene, scene_top2down, bbox_params, add_start_end=False,
+                   diffusion=False):
+        assert objects_dataset is futures and diffusion and not add_start_end
+        seen["folders"].append((folder, {k: tuple(v.shape) for k, v in bbox_params.items()}))
+    monkeypatch.setattr(script, "render_to_folder", rec_folder)
+
+    def rec_final(args, bbox_params, dataset, objects_dataset, classes, floor_plan, tr_floor, scene, scene_top2down, path_to_image, path_to_objs,
+                  filename, network_objae=None, device=None, diffusion=False):
+        seen["final"].append({k: tuple(v.shape) for k, v in bbox_params.items()})
+    monkeypatch.setattr(script, "render_scene_from_bbox_params", rec_final)
+    monkeypatch.setattr(script, "get_textured_objects", lambda *a, **k: ([], [], []))
+    monkeypatch.setattr(script, "get_textured_objects_based_on_objfeats", lambda *a, **k: ([], [], []))
+
+    np.random.seed(0)
+    argv = [str(cfg_path), str(tmp_path / "out"), str(tmp_path / "futures.pkl"), "--weight_file", str(weights), "--n_sequences", "2",
+            "--clip_denoised", "--no_texture", "--without_screen", "--num_partial", str(P)]
+    script.main(argv + (["--arrange_objects"] if mode == "arrange" else []))
+    assert len(seen["sample"]) == 2 and len(seen["final"]) == 2
+    # the network's dict: 4 kept objects, the reference's keys (class scores without the 'empty' column)
+    assert seen["final"][0] == {"class_labels": (1, 4, nc - 1), "translations": (1, 4, 3), "sizes": (1, 4, 3), "angles": (1, 4, 2),
+                                "objfeats": (1, 4, 32)}
+    if mode == "complete":
+        assert [f for f, _ in seen["folders"]] == ["partial", "partial"]
+        assert seen["folders"][0][1]["class_labels"] == (1, P, nc) and seen["folders"][0][1]["objfeats"] == (1, P, 32)
+    else:
+        # delete_empty_boxes ran on the noisy input: only the scene's real objects reach the renderer, classes without the 'empty' column
+        assert [f for f, _ in seen["folders"]] == ["noisy", "noisy"]
+        shapes = seen["folders"][0][1]
+        k = shapes["class_labels"][1]
+        assert 1 <= k <= N and shapes == {"class_labels": (1, k, nc - 1), "translations": (1, k, 3), "sizes": (1, k, 3), "angles": (1, k, 2),
+                                          "objfeats": (1, k, 32)}
