@@ -214,11 +214,13 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(const float* __re
 
 // ------------------------------------------------------------------------------------------------
 // Softmax attention core (mid_attn), one block of 256 threads per (scene, head).  K/V of the scene are staged in LDS
-// (36-float rows, 16-byte reads); FOUR lanes share a query token, each owning 8 of the 32 head channels: a score is
+// (36-float rows, 16-byte reads); the block has as many waves as the scene has 16-token groups (dsc_attention_threads: 320 threads at
+// N = 80 -- one pass over the queries instead of two with the second three quarters idle; 75 -> 4x us per launch).
+// FOUR lanes share a query token, each owning 8 of the 32 head channels: a score is
 // 8 FMAs + two wave shuffles across the quad, every lane of a quad walks the same key (LDS broadcast).  Two passes over
 // the keys (row maximum, then exp / sum / PV), i.e. the plain softmax of the reference (denoise_net.py:252-258).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(512) void attention_kernel(const float* __restrict__ q, int64_t ldq,
                                                         const float* __restrict__ k, int64_t ldk,
                                                         const float* __restrict__ v, int64_t ldv,
                                                         float* __restrict__ out, int64_t ldo, int n, float scale) {
@@ -229,14 +231,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const float* kb = k + (int64_t)b * n * ldk + h * 32;
     const float* vb = v + (int64_t)b * n * ldv + h * 32;
-    for (int f = tid; f < n * 8; f += 256) {
+    const int nthr = blockDim.x, rows = nthr >> 2;       // four lanes per query token (dsc_attention_threads)
+    for (int f = tid; f < n * 8; f += nthr) {
         const int j = f >> 3, c4 = (f & 7) * 4;
         *reinterpret_cast<f32x4*>(Ks + j * LP + c4) = *reinterpret_cast<const f32x4*>(kb + (int64_t)j * ldk + c4);
         *reinterpret_cast<f32x4*>(Vs + j * LP + c4) = *reinterpret_cast<const f32x4*>(vb + (int64_t)j * ldv + c4);
     }
     __syncthreads();
     const int part = tid & 3;
-    for (int i0 = 0; i0 < n; i0 += 64) {
+    for (int i0 = 0; i0 < n; i0 += rows) {
         const int i = i0 + (tid >> 2);
         const bool ok = i < n;
         const float* qr = q + ((int64_t)b * n + (ok ? i : 0)) * ldq + h * 32 + part * 8;
@@ -450,7 +453,7 @@ extern "C" int dsc_attention_f32(const float* q, int64_t ldq, const float* k, in
     if (!dsc_aligned16(q) || !dsc_aligned16(k) || !dsc_aligned16(v) || !dsc_aligned16(out) ||
         (ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DSC_EALIGN;
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(attention_kernel, dim3(scenes * DSC_HEADS), dim3(256), (size_t)2 * n * LP * sizeof(float),
+    hipLaunchKernelGGL(attention_kernel, dim3(scenes * DSC_HEADS), dim3(dsc_attention_threads(n)), (size_t)2 * n * LP * sizeof(float),
                        static_cast<hipStream_t>(stream), q, ldq, k, ldk, v, ldv, out, ldo, n, scale);
     DSC_LAUNCH_CHECK();
     return 0;

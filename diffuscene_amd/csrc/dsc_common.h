@@ -53,6 +53,14 @@ __device__ __forceinline__ float dsc_act(float x, int act) {
 // x phi(x) takes its Gaussian density from the exponential the erf approximation computes anyway (exp(-(x/sqrt2)^2) = exp(-x^2/2)) --
 // one v_rcp, one v_exp, ~14 FMAs; SiLU' uses the hardware reciprocal.  (Round-4 first form: libm expf twice + a division, ~45 VALU
 // per element: the fused launches lost to the epilogue what the removed activation-backward launches had saved.)
+// Block size of the softmax-attention kernels (forward: blocks.hip, backward: train.hip): four lanes per token, one pass over the
+// tokens whenever they fit 512 threads (N = 80: 320 threads, five waves; N <= 64: 256 as before), host side only.
+static inline unsigned dsc_attention_threads(int n) {
+    if (n <= 64) return 256;
+    const int waves = (n + 15) / 16;
+    return waves >= 8 ? 512u : 64u * (unsigned)waves;
+}
+
 __device__ __forceinline__ float dsc_act_grad(float xv, int act) {
     if (act == DSC_ACT_GELU) {
         const float a = fabsf(xv) * 0.70710678118654752440f;

@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(192) void attention_bwd_kernel(
 // Same backward for scenes of up to 96 tokens: the probabilities P and dS = P (dP - D) are kept in LDS instead of being
 // recomputed per key, and 4 lanes share a query / key (8 of the 32 head channels each, 16-byte LDS reads, quad shuffles).
 // LDS: Q (pre-scaled), K, V, dO as [n][36]; P, dS as [n][n+1].
-__global__ __launch_bounds__(256) void attention_bwd_cached_kernel(
+__global__ __launch_bounds__(512) void attention_bwd_cached_kernel(
         const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk, const float* __restrict__ v, long ldv,
         const float* __restrict__ dout, long ldo, float* __restrict__ dq, long lddq, float* __restrict__ dk, long lddk,
         float* __restrict__ dv, long lddv, int n, float scale) {
@@ -1224,7 +1224,8 @@ __global__ __launch_bounds__(256) void attention_bwd_cached_kernel(
     float* DS = P + n * PS;
     const int b = blockIdx.x >> 2, h = blockIdx.x & 3;
     const int tid = threadIdx.x, part = tid & 3;
-    for (int f = tid; f < n * 8; f += 256) {
+    const int nthr = blockDim.x, rows = nthr >> 2;       // four lanes per token (dsc_attention_threads)
+    for (int f = tid; f < n * 8; f += nthr) {
         const int j = f >> 3, c4 = (f & 7) * 4;
         const long row = (long)b * n + j;
         f32x4 qv = *reinterpret_cast<const f32x4*>(q + row * ldq + h * 32 + c4);
@@ -1248,7 +1249,7 @@ __global__ __launch_bounds__(256) void attention_bwd_cached_kernel(
         return s;
     };
     // phase 1: per query i -- P[i][:], D_i, dS[i][:], dq_i
-    for (int i0 = 0; i0 < n; i0 += 64) {
+    for (int i0 = 0; i0 < n; i0 += rows) {
         const int i = i0 + (tid >> 2);
         const bool ok = i < n;
         const int ic = ok ? i : 0;
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(256) void attention_bwd_cached_kernel(
     }
     __syncthreads();
     // phase 2: per key j -- dv_j = sum_i P_ij dO_i, dk_j = sum_i dS_ij Q_i (Q already carries the scale)
-    for (int j0 = 0; j0 < n; j0 += 64) {
+    for (int j0 = 0; j0 < n; j0 += rows) {
         const int j = j0 + (tid >> 2);
         const bool ok = j < n;
         const int jc = ok ? j : 0;
@@ -1631,7 +1632,7 @@ extern "C" int dsc_attention_bwd_f32(const float* q, int64_t ldq, const float* k
             attr_c = true;
         }
         DSC_CLEAR_STALE_ERROR();
-        hipLaunchKernelGGL(attention_bwd_cached_kernel, dim3(scenes * DSC_HEADS), dim3(256), ldc,
+        hipLaunchKernelGGL(attention_bwd_cached_kernel, dim3(scenes * DSC_HEADS), dim3(dsc_attention_threads(n)), ldc,
                            static_cast<hipStream_t>(stream), q, (long)ldq, k, (long)ldk, v, (long)ldv, dout, (long)ldo, dq,
                            (long)lddq, dk, (long)lddk, dv, (long)lddv, n, scale);
         DSC_LAUNCH_CHECK();
