@@ -140,7 +140,7 @@ def test_layernorm_backward():
     assert rel(gx.grad, xd.grad) < 5e-6 and rel(gg.grad, gd.grad) < 5e-6 and rel(gr.grad, rd.grad) < 1e-7
 
 
-@pytest.mark.parametrize("B,N", [(3, 80), (2, 12), (1, 160)])
+@pytest.mark.parametrize("B,N", [(3, 80), (2, 12), (1, 160), (2, 70), (2, 96)])   # cached softmax backward: 320 / 256 threads, (uncached kernel), 320 ragged, 384
 def test_attention_cores_backward(B, N):
     from diffuscene_amd.autograd_ops import AttentionFn, LinearAttentionCrossFn, LinearAttentionSelfFn
     qkv, dy = rnd(B * N, 384, seed=29) * 2, rnd(B * N, 128, seed=30)
