@@ -79,3 +79,36 @@ def test_bench_self_spawns_one_rank_per_gpu():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True,
                         timeout=120)
     assert r2.returncode != 0
+
+
+def test_bench_side_line_child_contains_failures(monkeypatch):
+    """bench.side_line_child: whatever happens in a side line's child process (GPU fault -> abort, exception, hang) becomes an
+    {"error": ...} entry of the parent's record; a clean child contributes the JSON line it printed (after any library chatter)."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class R:
+        def __init__(self, rc, out, err=""):
+            self.returncode, self.stdout, self.stderr = rc, out, err
+    seen = []
+
+    def fake_run(cmd, env=None, capture_output=None, text=None, timeout=None):
+        seen.append((cmd, env))
+        return results.pop(0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("RANK", "0")
+    results = [R(0, 'RCCL version ...\n{"steps_per_s": 101.5, "workload": "x"}\ntrailing chatter\n')]
+    assert bench.side_line_child("arrange") == {"steps_per_s": 101.5, "workload": "x"}
+    cmd, env = seen[-1]
+    assert cmd[-2:] == ["--side-line", "arrange"] and "RANK" not in env              # a single-GPU child, whatever launched the parent
+    results = [R(-6, "", "Memory access fault by GPU node-2 (Agent handle: 0x1) on address 0x7000. Reason: Unknown.\n")]
+    out = bench.side_line_child("living80:f32")
+    assert set(out) == {"error"} and "exit code -6" in out["error"] and "Memory access fault" in out["error"]
+    results = [R(0, "no json here\n")]
+    assert "error" in bench.side_line_child("text")
+
+    def hang(cmd, env=None, capture_output=None, text=None, timeout=None):
+        raise subprocess.TimeoutExpired(cmd, timeout)
+    monkeypatch.setattr(subprocess, "run", hang)
+    assert bench.side_line_child("complete", timeout=7) == {"error": "timed out after 7 s"}
