@@ -1,0 +1,63 @@
+"""tests/golden/meantypes.npz: the REAL reference run with the other two prediction types of GaussianDiffusion (build container only).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Usage:  python -m oracle.make_golden_meantypes     (~2 minutes)
+
+Every other golden of this repo uses model_mean_type='v' (the `_v` YAMLs).  Three of the twelve shipped configs
+(config/uncond/diffusion_*_instancond_lat32_eps.yaml) train and sample with 'eps'; 'x0' is the third branch of
+diffusion_ddpm.py:248-262 (model_predictions) / :536-545 (the p_losses target).  Per type, on the bedroom network of
+oracle/make_golden.CASES with seeded weights and inputs:
+  * p_losses with loss_separate + the IoU term (B = 2): per-scene losses, the logged terms, gradient norms of every parameter
+    and three gradient slices;
+  * a T = 50 reverse chain with replayed noise, clipped and unclipped (the clip acts on x0, which each type derives differently).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+from . import weights as W
+from .make_golden import GOLDEN, Replay, build_ref, case_inputs, noise_list
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    stats_file = os.path.join(tempfile.mkdtemp(), "dataset_stats.txt")
+    with open(stats_file, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    out = {}
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    T = 50
+    for mt in ("eps", "x0"):
+        net, diff = build_ref(kw, time_num=1000, model_mean_type=mt, loss_separate=True, loss_iou=True, train_stats_file=stats_file)
+        noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+        with contextlib.redirect_stdout(io.StringIO()):
+            losses, scal = diff.diffusion.p_losses(diff._denoise, x, t, noise=noise, condition=cond, condition_cross=None)
+        losses.mean().backward()
+        out[mt + ".losses"] = losses.detach().numpy()
+        for k, v in scal.items():
+            out[mt + "." + k] = np.float32(v.item())
+        out[mt + ".grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
+        out[mt + ".grad.init_conv.bias"] = net.init_conv.bias.grad.numpy().copy()
+        out[mt + ".grad.mid_attn.to_qkv"] = net.mid_attn.fn.fn.to_qkv.weight.grad.numpy()[:8, :16, 0].copy()
+        out[mt + ".grad.final.block2.proj"] = net.final_res_block.block2.proj.weight.grad.numpy()[:8, :16, 0].copy()
+        print(mt, "p_losses", losses.detach().numpy(), {k: round(float(v), 5) for k, v in scal.items()})
+        net, diff = build_ref(kw, time_num=T, model_mean_type=mt)
+        for clip, seed, tag in ((True, 11, "clip"), (False, 12, "noclip")):
+            seq = noise_list([(B, N, C)] * (T + 1), seed, "mt_%s_" % tag)
+            with torch.no_grad():
+                s = diff.gen_samples((B, N, C), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=clip)
+            out["%s.T50.%s" % (mt, tag)] = s.numpy()
+            print(mt, "chain T=50", tag, float(s.abs().mean()), float(s.abs().max()))
+    np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
+    print("written", os.path.join(GOLDEN, "meantypes.npz"))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

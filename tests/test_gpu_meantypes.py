@@ -1,0 +1,107 @@
+"""GPU: the other two prediction types of GaussianDiffusion -- 'eps' (three of the twelve shipped configs,
+config/uncond/*_eps.yaml) and 'x0' -- against outputs of the REAL reference (tests/golden/meantypes.npz, oracle/make_golden_meantypes.py).
+Every other real-reference golden uses 'v'.  Per type: p_losses with the IoU term through the autograd path AND through the static
+training plan (losses, logged terms, gradient norms of all parameters, three gradient slices), and a T = 50 reverse chain with
+replayed noise, clipped and unclipped, eager and replayed from the hipGraph.  Tolerances as everywhere: 1e-4 on outputs and losses,
+1e-3 on gradient norms (the reference's own fp32 CPU gradients are 2.6e-4 from an fp64 evaluation)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import weights as W  # noqa: E402
+from oracle.make_golden import case_inputs, noise_list  # noqa: E402
+
+from test_gpu_wide import check, dev  # noqa: E402
+
+_PART_KEYS = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class', 'loss.object', 'loss.objfeat', 'loss.liou',
+              'loss.bbox_iou')
+
+
+def _model(tmp_path, mean_type, time_num):
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    kw = W.UNCOND_BEDROOM
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    net = Unet1D(**kw)
+    net.load_state_dict(W.synth_state_dict(kw))
+    net.to(dev())
+    cfg = dict(objectness_dim=0, class_dim=kw["class_dim"], angle_dim=2, objfeat_dim=32)
+    return net, DiffusionPoint(net, cfg, time_num=time_num, model_mean_type=mean_type, loss_separate=True, loss_iou=True,
+                               train_stats_file=str(stats))
+
+
+def _grad_checks(g, mt, names, grad_of, what):
+    gn = np.array([float(grad_of(k).norm()) for k in names])
+    ref = g[mt + ".grad_norms"]
+    e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+    print("%s %s: grad-norm rel err vs the reference's fp32 CPU gradients: max %.3g at %s" % (mt, what, e.max(), names[int(e.argmax())]))
+    assert e.max() < 1e-3, (mt, what, names[int(e.argmax())], e.max())
+    check(grad_of("init_conv.bias"), g[mt + ".grad.init_conv.bias"], "%s %s d init_conv.bias" % (mt, what))
+    check(grad_of("mid_attn.fn.fn.to_qkv.weight")[:8, :16, 0], g[mt + ".grad.mid_attn.to_qkv"], "%s %s d mid_attn.to_qkv" % (mt, what))
+    check(grad_of("final_res_block.block2.proj.weight")[:8, :16, 0], g[mt + ".grad.final.block2.proj"], "%s %s d final.block2.proj" % (mt, what))
+
+
+@pytest.mark.parametrize("mean_type", ["eps", "x0"])
+def test_p_losses_and_gradients(golden_dir, tmp_path, mean_type):
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.train_plan import HipBackend, TrainPlan
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    net, diff = _model(tmp_path, mean_type, 1000)
+    names = [k for k, _ in net.named_parameters()]
+    assert len(names) == len(g[mean_type + ".grad_norms"])
+    # autograd path
+    losses, scal = diff.diffusion.p_losses(diff._denoise, x.to(dev()), t.to(dev()), noise=noise.to(dev()), condition=cond.to(dev()),
+                                           condition_cross=None)
+    losses.mean().backward()
+    check(losses, g[mean_type + ".losses"], "%s p_losses (autograd path)" % mean_type)
+    for k, v in scal.items():
+        want = float(g[mean_type + "." + k])
+        assert abs(float(v.detach()) - want) <= 1e-4 * max(1.0, abs(want)), (mean_type, k, float(v.detach()), want)
+    params = dict(net.named_parameters())
+    _grad_checks(g, mean_type, names, lambda k: params[k].grad, "autograd path")
+    # static training plan (what train_on_batch runs)
+    for p in net.parameters():
+        p.grad = None
+    flat = FlatStorage(net)
+    B, N, C = x.shape
+    plan = TrainPlan(net, flat, diff.diffusion, B, N, SS_PER_SLOT, 128, 0, 0, HipBackend(dev()))
+    plan.x0.copy_(x.to(dev())); plan.noise.copy_(noise.to(dev())); plan.t.copy_(t.to(dev()))
+    plan.ctx_in.t.copy_(cond[0].to(dev()))
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    torch.cuda.synchronize()
+    check(plan.losses, g[mean_type + ".losses"], "%s p_losses (training plan)" % mean_type)
+    means = plan.parts.mean(dim=0).cpu()
+    for i, k in enumerate(_PART_KEYS):
+        want = float(g[mean_type + "." + k])
+        assert abs(float(means[i]) - want) <= 1e-4 * max(1.0, abs(want)), (mean_type, k, float(means[i]), want)
+    params = dict(net.named_parameters())
+    _grad_checks(g, mean_type, names, lambda k: flat.grad_view(params[k]), "training plan")
+
+
+@pytest.mark.parametrize("mean_type", ["eps", "x0"])
+def test_reverse_chain(golden_dir, tmp_path, mean_type):
+    from diffuscene_amd.sampler import NoiseReplay
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    net, diff = _model(tmp_path, mean_type, 50)
+    cd = cond.to(dev())
+    for clip, seed, tag in ((True, 11, "clip"), (False, 12, "noclip")):
+        seq = torch.stack(noise_list([(B, N, C)] * 51, seed, "mt_%s_" % tag)).to(dev())
+        with torch.no_grad():
+            eager = diff.gen_samples((B, N, C), dev(), condition=cd, noise_fn=NoiseReplay(seq), clip_denoised=clip, graph=False)
+            graph = diff.gen_samples((B, N, C), dev(), condition=cd, noise_fn=NoiseReplay(seq), clip_denoised=clip, graph=True)
+        assert torch.equal(eager, graph), "the captured step must reproduce the eager loop bit for bit"
+        check(eager, g["%s.T50.%s" % (mean_type, tag)], "%s T=50 chain (%s)" % (mean_type, tag))

@@ -87,6 +87,29 @@ def test_reverse_chain_T50_matches_reference(golden_dir):
         assert _rel(s, g["complete_T50"]) < 1e-4
 
 
+@pytest.mark.parametrize("mean_type", ["eps", "x0"])
+def test_other_prediction_types_match_reference(golden_dir, mean_type):
+    """'eps' (config/uncond/*_eps.yaml) and 'x0': the restatement's p_losses and T = 50 chains vs the REAL reference
+    (tests/golden/meantypes.npz, oracle/make_golden_meantypes.py); every other golden uses 'v'."""
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    sd = W.synth_state_dict(kw)
+    den = lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None)
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    with torch.no_grad():
+        lw, scal, _ = R.p_losses(R.schedule_tables(1e-4, 0.02, 1000, mean_type), den, x, t, noise, R.dims_from_kwargs(kw), loss_separate=True,
+                                 loss_iou=True, stats=W.DATASET_STATS, mean_type=mean_type)
+        assert _rel(lw, g[mean_type + ".losses"]) < RTOL
+        for k, v in scal.items():
+            ref = float(g[mean_type + "." + k])
+            assert abs(float(v) - ref) <= RTOL * max(1.0, abs(ref)), k
+        tb = R.schedule_tables(1e-4, 0.02, 50, mean_type)
+        for clip, seed, tag in ((True, 11, "clip"), (False, 12, "noclip")):
+            s = R.p_sample_loop(tb, den, (B, N, C), noise_list([(B, N, C)] * 51, seed, "mt_%s_" % tag), 50, clip, mean_type=mean_type)
+            assert _rel(s, g["%s.T50.%s" % (mean_type, tag)]) < 1e-4, (mean_type, tag)
+
+
 def test_text_and_arrange_chains_match_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "chains.npz"))
     kw, x, t, cond, cross = case_inputs("text_bedroom")
