@@ -617,11 +617,12 @@ def main():
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("DSC_BENCH_DRYRUN"):          # launcher plumbing only (CPU test): what each rank would run
-        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "world": ws, "gpus": args.gpus,
+        sys.stdout.write(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": local, "world": ws, "gpus": args.gpus,
                           "config": args.config, "scaling": args.scaling, "master": os.environ.get("MASTER_ADDR"),
                           "ddp_flush": os.environ.get("DSC_DDP_FLUSH", "block"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                           "batch_per_rank": (CONFIGS[args.config]["batch"] // ws) if args.scaling == "strong"
-                          else CONFIGS[args.config]["batch"]}), flush=True)
+                          else CONFIGS[args.config]["batch"]}) + "\n")        # ONE write per rank: the ranks share a pipe, print() would emit the newline separately
+        sys.stdout.flush()
         if ws != args.gpus:
             raise SystemExit(2)
         return

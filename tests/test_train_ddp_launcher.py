@@ -54,6 +54,21 @@ def test_launcher_shards_loader_and_redirects_rank_outputs(tmp_path):
     assert recs[0]["passes"][0] != recs[0]["passes"][1]               # a new permutation on every pass
 
 
+def _json_objects(text):
+    """Every JSON object in the ranks' shared stdout (two ranks may land on one line)."""
+    dec, out = json.JSONDecoder(), []
+    for line in text.splitlines():
+        i = line.find("{")
+        while i >= 0:
+            try:
+                obj, end = dec.raw_decode(line, i)
+            except ValueError:
+                break
+            out.append(obj)
+            i = line.find("{", end)
+    return out
+
+
 def test_bench_self_spawns_one_rank_per_gpu():
     """`python bench.py --gpus N` from a plain shell (how the driver calls it) re-executes itself under torch.distributed.run
     with N ranks on 127.0.0.1; DSC_BENCH_DRYRUN stops every rank before it touches a GPU."""
@@ -62,7 +77,7 @@ def test_bench_self_spawns_one_rank_per_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--scaling", "strong"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    recs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    recs = sorted(_json_objects(r.stdout), key=lambda d: d["rank"])
     assert [d["rank"] for d in recs] == [0, 1] and all(d["world"] == 2 and d["gpus"] == 2 for d in recs)
     assert [d["local_rank"] for d in recs] == [0, 1] and all(d["master"] == "127.0.0.1" and d["scaling"] == "strong" for d in recs)
     assert all(d["batch_per_rank"] == 128 and d["ddp_flush"] == "block" and d["ipc_legacy"] == "0" for d in recs)
@@ -71,7 +86,7 @@ def test_bench_self_spawns_one_rank_per_gpu():
     r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", "strong"],
                         env=dict(env, DSC_DDP_FLUSH="end"), capture_output=True, text=True, timeout=600)
     assert r8.returncode == 0, r8.stdout + r8.stderr
-    recs8 = sorted((json.loads(l) for l in r8.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    recs8 = sorted(_json_objects(r8.stdout), key=lambda d: d["rank"])
     assert [d["local_rank"] for d in recs8] == list(range(8)) and all(d["world"] == 8 and d["gpus"] == 8 for d in recs8)
     assert all(d["batch_per_rank"] == 32 and d["ddp_flush"] == "end" and d["scaling"] == "strong" for d in recs8)
     # under torchrun with a mismatching --gpus the script refuses instead of running a wrong configuration
