@@ -9,6 +9,7 @@ oracle/make_golden.CASES with seeded weights and inputs:
   * p_losses with loss_separate + the IoU term (B = 2): per-scene losses, the logged terms, gradient norms of every parameter
     and three gradient slices;
   * a T = 50 reverse chain with replayed noise, clipped and unclipped (the clip acts on x0, which each type derives differently).
+Plus one T = 50 chain with model_var_type='fixedlarge' (the other variance branch of p_mean_variance, :314-321).
 """
 import contextlib
 import io
@@ -55,6 +56,14 @@ def main():
                 s = diff.gen_samples((B, N, C), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=clip)
             out["%s.T50.%s" % (mt, tag)] = s.numpy()
             print(mt, "chain T=50", tag, float(s.abs().mean()), float(s.abs().max()))
+    # model_var_type='fixedlarge' (diffusion_ddpm.py:314-321: sigma_t^2 = beta_t, the log-variance of step 0 taken from the posterior): the
+    # other variance branch of p_mean_variance; no shipped config selects it, the product implements it (tb["_sigma_large"])
+    net, diff = build_ref(kw, time_num=T, model_mean_type="v", model_var_type="fixedlarge")
+    seq = noise_list([(B, N, C)] * (T + 1), 13, "mt_large_")
+    with torch.no_grad():
+        s = diff.gen_samples((B, N, C), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=True)
+    out["fixedlarge.T50.clip"] = s.numpy()
+    print("fixedlarge chain T=50", float(s.abs().mean()), float(s.abs().max()))
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

@@ -105,3 +105,24 @@ def test_reverse_chain(golden_dir, tmp_path, mean_type):
             graph = diff.gen_samples((B, N, C), dev(), condition=cd, noise_fn=NoiseReplay(seq), clip_denoised=clip, graph=True)
         assert torch.equal(eager, graph), "the captured step must reproduce the eager loop bit for bit"
         check(eager, g["%s.T50.%s" % (mean_type, tag)], "%s T=50 chain (%s)" % (mean_type, tag))
+
+
+def test_fixedlarge_variance_chain(golden_dir, tmp_path):
+    """model_var_type='fixedlarge' (sigma_t^2 = beta_t; diffusion_ddpm.py:314-321): the other variance branch, T = 50, eager and graph."""
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.sampler import NoiseReplay
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N, C = x.shape
+    net = Unet1D(**kw)
+    net.load_state_dict(W.synth_state_dict(kw))
+    net.to(dev())
+    diff = DiffusionPoint(net, dict(objectness_dim=0, class_dim=kw["class_dim"], angle_dim=2, objfeat_dim=32), time_num=50,
+                          model_mean_type="v", model_var_type="fixedlarge")
+    seq = torch.stack(noise_list([(B, N, C)] * 51, 13, "mt_large_")).to(dev())
+    with torch.no_grad():
+        eager = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=False)
+        graph = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=True)
+    assert torch.equal(eager, graph)
+    check(eager, g["fixedlarge.T50.clip"], "fixedlarge T=50 chain")
