@@ -64,6 +64,14 @@ def main():
         s = diff.gen_samples((B, N, C), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=True)
     out["fixedlarge.T50.clip"] = s.numpy()
     print("fixedlarge chain T=50", float(s.abs().mean()), float(s.abs().max()))
+    # the warm-up beta schedules of get_betas (diffusion_ddpm.py:62-79; 'cosine' never assigns betas there) with the tables
+    # GaussianDiffusion derives from them, for 'eps' (the only type that adds tables of its own to the common set)
+    for sched in ("warm0.1", "warm0.2", "warm0.5"):
+        _, diff = build_ref(kw, time_num=1000, model_mean_type="eps", schedule_type=sched)
+        gd = diff.diffusion
+        for k in ("betas", "alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2", "loss_weight"):
+            out["%s.%s" % (sched, k)] = getattr(gd, k).numpy()
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

@@ -52,6 +52,19 @@ def test_schedule_tables_bit_identical_to_reference(golden_dir):
         get_betas("cosine", 1e-4, 0.02, 10)
 
 
+@pytest.mark.parametrize("sched", ["warm0.1", "warm0.2", "warm0.5"])
+def test_warmup_schedules_bit_identical_to_reference(golden_dir, sched):
+    """The warm-up beta schedules of get_betas (reference diffusion_ddpm.py:62-79) and every table GaussianDiffusion derives from
+    them, against the REAL reference's (tests/golden/meantypes.npz, oracle/make_golden_meantypes.py): bit for bit."""
+    from diffuscene_amd.networks.diffusion_ddpm import GaussianDiffusion, get_betas
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    d = GaussianDiffusion({}, get_betas(sched, 1e-4, 0.02, 1000), "mse", "eps", "fixedsmall", True, False, None)
+    keys = [k[len(sched) + 1:] for k in g.files if k.startswith(sched + ".")]
+    assert len(keys) == 9
+    for k in keys:
+        assert np.array_equal(getattr(d, k).numpy(), g[sched + "." + k]), (sched, k)
+
+
 def test_no_cpu_fallback():
     from diffuscene_amd import ops
     from diffuscene_amd.networks.denoise_net import Unet1D
