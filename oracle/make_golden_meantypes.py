@@ -72,6 +72,26 @@ def main():
         for k in ("betas", "alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
                   "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2", "loss_weight"):
             out["%s.%s" % (sched, k)] = getattr(gd, k).numpy()
+    # the small closed-form helpers every branch above is built from (diffusion_ddpm.py:217-241, 267-303) and model_predictions (:242-265)
+    # with its clip / rederive switches, on their own: seeded tensors, T = 1000
+    hx, ht = case_inputs("uncond_bedroom")[1], torch.tensor([0, 999], dtype=torch.int64)
+    h1, h2 = W.synth_noise(tuple(hx.shape), 21, "helper_a"), W.synth_noise(tuple(hx.shape), 22, "helper_b")
+    for mt in ("v", "eps", "x0"):
+        net, diff = build_ref(kw, time_num=1000, model_mean_type=mt)
+        gd = diff.diffusion
+        with torch.no_grad():
+            if mt == "v":
+                res = {"q_mean_variance": gd.q_mean_variance(hx, ht), "q_posterior_mean_variance": gd.q_posterior_mean_variance(hx, h1, ht),
+                       "_predict_xstart_from_eps": (gd._predict_xstart_from_eps(h1, ht, h2),), "_predict_eps_from_start": (gd._predict_eps_from_start(h1, ht, hx),),
+                       "_predict_v": (gd._predict_v(hx, ht, h2),), "_predict_start_from_v": (gd._predict_start_from_v(h1, ht, h2),)}
+                for k, vs in res.items():
+                    for i, v in enumerate(vs):
+                        out["helper.%s.%d" % (k, i)] = (v * torch.ones_like(hx) if v.shape != hx.shape else v).numpy()
+            for clip in (False, True):
+                for rederive in (False, True):
+                    mp = gd.model_predictions(diff._denoise, h1, ht, cond, None, clip_x_start=clip, rederive_pred_noise=rederive)
+                    out["helper.model_predictions.%s.clip%d.rederive%d.pred_noise" % (mt, clip, rederive)] = mp.pred_noise.numpy()
+                    out["helper.model_predictions.%s.clip%d.rederive%d.pred_x_start" % (mt, clip, rederive)] = mp.pred_x_start.numpy()
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

@@ -126,3 +126,32 @@ def test_fixedlarge_variance_chain(golden_dir, tmp_path):
         graph = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=True)
     assert torch.equal(eager, graph)
     check(eager, g["fixedlarge.T50.clip"], "fixedlarge T=50 chain")
+
+
+def test_closed_form_helpers_and_model_predictions(golden_dir, tmp_path):
+    """q_mean_variance, q_posterior_mean_variance, the four _predict_* conversions (reference diffusion_ddpm.py:217-241, 267-303) and
+    model_predictions (:242-265) for every prediction type with its clip / rederive switches, on seeded tensors at t = 0 and t = 999."""
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, _, cond, _ = case_inputs("uncond_bedroom")
+    ht = torch.tensor([0, 999], dtype=torch.int64, device=dev())
+    hx = x.to(dev())
+    h1, h2 = W.synth_noise(tuple(x.shape), 21, "helper_a").to(dev()), W.synth_noise(tuple(x.shape), 22, "helper_b").to(dev())
+    cd = cond.to(dev())
+    for mt in ("v", "eps", "x0"):
+        net, diff = _model(tmp_path, mt, 1000)
+        gd = diff.diffusion
+        with torch.no_grad():
+            if mt == "v":
+                res = {"q_mean_variance": gd.q_mean_variance(hx, ht), "q_posterior_mean_variance": gd.q_posterior_mean_variance(hx, h1, ht),
+                       "_predict_xstart_from_eps": (gd._predict_xstart_from_eps(h1, ht, h2),), "_predict_eps_from_start": (gd._predict_eps_from_start(h1, ht, hx),),
+                       "_predict_v": (gd._predict_v(hx, ht, h2),), "_predict_start_from_v": (gd._predict_start_from_v(h1, ht, h2),)}
+                for k, vs in res.items():
+                    for i, v in enumerate(vs):
+                        v = v * torch.ones_like(hx) if v.shape != hx.shape else v
+                        check(v, g["helper.%s.%d" % (k, i)], "%s[%d]" % (k, i), tol=2e-6)
+            for clip in (False, True):
+                for rederive in (False, True):
+                    mp = gd.model_predictions(diff._denoise, h1, ht, cd, None, clip_x_start=clip, rederive_pred_noise=rederive)
+                    tag = "helper.model_predictions.%s.clip%d.rederive%d." % (mt, clip, rederive)
+                    check(mp.pred_noise, g[tag + "pred_noise"], tag + "pred_noise")
+                    check(mp.pred_x_start, g[tag + "pred_x_start"], tag + "pred_x_start")
