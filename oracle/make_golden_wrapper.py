@@ -22,7 +22,8 @@ right after ``torch.manual_seed(seed)``.  The GPU tests patch torch.randint / to
 move the result to the device, so identical draws in identical ORDER are part of what is pinned.
 Per case, stored: the target / condition / condition_cross handed to ``get_loss_iter``, loss + logged terms of ``get_loss``,
 ``train_on_batch`` (loss, gradient norm, parameter deltas of 12 parameters after one Adam step), raw ``sample`` outputs at B=4 with
-T=20, and the post-filtered dicts of generate_layout / complete_scene / arrange_scene at batch_size 1.
+T=20, the post-filtered dicts of generate_layout / complete_scene / arrange_scene at batch_size 1, and (uncond) the dict of dicts of
+generate_layout_progressive.
 """
 import contextlib
 import copy
@@ -231,6 +232,14 @@ def main():
                 d = m.generate_layout(room[:1], N, C, batch_size=1, clip_denoised=False, keep_empty=True)
             for k, v in d.items():
                 out["uncond.layout_noclip_keep." + k] = v.numpy()
+            # the progressive entry point (:320-333): the trajectory of the reverse loop, every 5th step post-filtered on its own
+            torch.manual_seed(SEED_ONE + 20)
+            with quiet:
+                traj = m.generate_layout_progressive(room[:1], N, C, batch_size=1, ret_traj=True, clip_denoised=True, num_step=5)
+            keys["uncond.progressive_steps"] = sorted(int(k) for k in traj)
+            for kt, dd in traj.items():
+                for k, v in dd.items():
+                    out["uncond.progressive.%d.%s" % (kt, k)] = v.numpy()
         print("%-8s sample |mean| %.5f, layout boxes kept %d of %d" % (case, float(y.abs().mean()), d["translations"].shape[1], N))
     with open(os.path.join(GOLDEN, "wrapper_keys.json"), "w") as f:
         json.dump(keys, f)

@@ -221,3 +221,14 @@ def test_sample_and_layout_entry_points(case, golden_dir, tmp_path, cpu_rng):
             d = m.generate_layout(room[:1], N, C, batch_size=1, clip_denoised=False, keep_empty=True)
         for k, v in d.items():
             check(v, g["uncond.layout_noclip_keep." + k], "uncond layout (unclipped, keep_empty) " + k)
+        # the progressive entry point (reference :320-333): the loop's trajectory, every 5th step post-filtered on its own
+        steps = json.load(open(os.path.join(golden_dir, "wrapper_keys.json")))["uncond.progressive_steps"]
+        torch.manual_seed(SEED_ONE + 20)
+        with quiet:
+            traj = m.generate_layout_progressive(room[:1], N, C, batch_size=1, ret_traj=True, clip_denoised=True, num_step=5)
+        assert sorted(traj) == steps == [0, 5, 10, 15, 20]
+        for kt, d in traj.items():
+            assert set(d) == {k.rsplit(".", 1)[1] for k in g.files if k.startswith("uncond.progressive.%d." % kt)}
+            for k, v in d.items():
+                assert v.device.type == "cpu"
+                check(v, g["uncond.progressive.%d.%s" % (kt, k)], "uncond generate_layout_progressive step %d %s" % (kt, k))
