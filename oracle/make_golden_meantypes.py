@@ -92,6 +92,26 @@ def main():
                     mp = gd.model_predictions(diff._denoise, h1, ht, cond, None, clip_x_start=clip, rederive_pred_noise=rederive)
                     out["helper.model_predictions.%s.clip%d.rederive%d.pred_noise" % (mt, clip, rederive)] = mp.pred_noise.numpy()
                     out["helper.model_predictions.%s.clip%d.rederive%d.pred_x_start" % (mt, clip, rederive)] = mp.pred_x_start.numpy()
+    # objectness_dim = 1 (no shipped YAML sets it; the reference's older encodings do: an extra channel between the class scores and the
+    # latent code, its own encoder / decoder MLP in Unet1D -- denoise_net.py:513-516,580-583 -- and its own loss / IoU-mask branch in
+    # p_losses -- diffusion_ddpm.py:578-583,591-595,613-616): forward, p_losses with the IoU term, three gradient slices
+    kwo = dict(kw, objectness_dim=1, channels=kw["channels"] + 1)
+    xo = torch.cat([x[:, :, :8 + kw["class_dim"]], torch.where(x[:, :, 8 + kw["class_dim"] - 1:8 + kw["class_dim"]] > 0, -1.0, 1.0),
+                    x[:, :, 8 + kw["class_dim"]:]], dim=-1).contiguous()           # objectness = +1 on real objects, -1 on empty slots
+    net, diff = build_ref(kwo, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=stats_file)
+    with torch.no_grad():
+        out["objectness.forward"] = net(xo, t, cond, None).numpy()
+    noise = W.synth_noise(tuple(xo.shape), 0, "train_noise_obj")
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses, scal = diff.diffusion.p_losses(diff._denoise, xo, t, noise=noise, condition=cond, condition_cross=None)
+    losses.mean().backward()
+    out["objectness.losses"] = losses.detach().numpy()
+    for k, v in scal.items():
+        out["objectness." + k] = np.float32(v.item())
+    out["objectness.grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
+    out["objectness.grad.objectness_embedf.0"] = net.objectness_embedf[0].weight.grad.numpy()[:, :, 0].copy()
+    out["objectness.grad.objectness_hidden2output.4"] = net.objectness_hidden2output[4].weight.grad.numpy()[:, :64, 0].copy()
+    print("objectness p_losses", losses.detach().numpy(), {k: round(float(v), 5) for k, v in scal.items()})
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

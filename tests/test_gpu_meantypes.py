@@ -155,3 +155,64 @@ def test_closed_form_helpers_and_model_predictions(golden_dir, tmp_path):
                     tag = "helper.model_predictions.%s.clip%d.rederive%d." % (mt, clip, rederive)
                     check(mp.pred_noise, g[tag + "pred_noise"], tag + "pred_noise")
                     check(mp.pred_x_start, g[tag + "pred_x_start"], tag + "pred_x_start")
+
+
+def test_objectness_channel(golden_dir, tmp_path):
+    """objectness_dim = 1: an extra channel with its own encoder / decoder MLP (reference denoise_net.py:513-516,580-583) and its own loss
+    and IoU-mask branch (diffusion_ddpm.py:578-583,591-595,613-616).  No shipped YAML sets it; the reference implements it, so does the
+    product: forward, p_losses through the autograd path and through the training plan."""
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.train_plan import HipBackend, TrainPlan
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    nc = kw["class_dim"]
+    kwo = dict(kw, objectness_dim=1, channels=kw["channels"] + 1)
+    xo = torch.cat([x[:, :, :8 + nc], torch.where(x[:, :, 8 + nc - 1:8 + nc] > 0, -1.0, 1.0), x[:, :, 8 + nc:]], dim=-1).contiguous()
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    net = Unet1D(**kwo)
+    net.load_state_dict(W.synth_state_dict(kwo))
+    net.to(dev())
+    diff = DiffusionPoint(net, dict(objectness_dim=1, class_dim=nc, angle_dim=2, objfeat_dim=32), time_num=1000, model_mean_type="v",
+                          loss_separate=True, loss_iou=True, train_stats_file=str(stats))
+    with torch.no_grad():
+        check(net(xo.to(dev()), t.to(dev()), cond.to(dev()), None), g["objectness.forward"], "objectness forward")
+    noise = W.synth_noise(tuple(xo.shape), 0, "train_noise_obj")
+    names = [k for k, _ in net.named_parameters()]
+    ref = g["objectness.grad_norms"]
+    assert len(names) == len(ref)
+
+    def verify(what, losses, parts, grad_of):
+        check(losses, g["objectness.losses"], "objectness p_losses (%s)" % what)
+        for k, v in parts.items():
+            want = float(g["objectness." + k])
+            assert abs(float(v) - want) <= 1e-4 * max(1.0, abs(want)), (what, k, float(v), want)
+        gn = np.array([float(grad_of(k).norm()) for k in names])
+        e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+        print("objectness %s: grad-norm rel err max %.3g at %s" % (what, e.max(), names[int(e.argmax())]))
+        assert e.max() < 1e-3, (what, names[int(e.argmax())], e.max())
+        check(grad_of("objectness_embedf.0.weight")[:, :, 0], g["objectness.grad.objectness_embedf.0"], "objectness %s d embedf.0" % what)
+        check(grad_of("objectness_hidden2output.4.weight")[:, :64, 0], g["objectness.grad.objectness_hidden2output.4"], "objectness %s d hidden2output.4" % what)
+
+    losses, scal = diff.diffusion.p_losses(diff._denoise, xo.to(dev()), t.to(dev()), noise=noise.to(dev()), condition=cond.to(dev()), condition_cross=None)
+    losses.mean().backward()
+    params = dict(net.named_parameters())
+    verify("autograd path", losses, {k: v.detach() for k, v in scal.items()}, lambda k: params[k].grad)
+    for p in net.parameters():
+        p.grad = None
+    flat = FlatStorage(net)
+    B, N, C = xo.shape
+    plan = TrainPlan(net, flat, diff.diffusion, B, N, SS_PER_SLOT, 128, 0, 0, HipBackend(dev()))
+    plan.x0.copy_(xo.to(dev())); plan.noise.copy_(noise.to(dev())); plan.t.copy_(t.to(dev()))
+    plan.ctx_in.t.copy_(cond[0].to(dev()))
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    torch.cuda.synchronize()
+    means = plan.parts.mean(dim=0).cpu()
+    params = dict(net.named_parameters())
+    verify("training plan", plan.losses, {k: means[i] for i, k in enumerate(_PART_KEYS)}, lambda k: flat.grad_view(params[k]))
