@@ -112,6 +112,32 @@ def main():
     out["objectness.grad.objectness_embedf.0"] = net.objectness_embedf[0].weight.grad.numpy()[:, :, 0].copy()
     out["objectness.grad.objectness_hidden2output.4"] = net.objectness_hidden2output[4].weight.grad.numpy()[:, :64, 0].copy()
     print("objectness p_losses", losses.detach().numpy(), {k: round(float(v), 5) for k, v in scal.items()})
+    # loss_separate = False (every shipped YAML sets True): the plain mean over all channels (diffusion_ddpm.py:563-566 for the
+    # re-arrangement layout, :597-600 for the full layout), logged terms unchanged; 'v', no IoU term
+    net, diff = build_ref(kw, time_num=1000, model_mean_type="v", loss_separate=False, loss_iou=False)
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise")
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses, scal = diff.diffusion.p_losses(diff._denoise, x, t, noise=noise, condition=cond, condition_cross=None)
+    losses.mean().backward()
+    out["flat.losses"] = losses.detach().numpy()
+    for k, v in scal.items():
+        out["flat." + k] = np.float32(v.item())
+    out["flat.grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
+    print("loss_separate=False p_losses", losses.detach().numpy())
+    kwr, xr, tr_, condr, _ = case_inputs("rearrange_living")
+    for sep in (True, False):
+        net, diff = build_ref(kwr, time_num=1000, model_mean_type="v", loss_separate=sep, loss_iou=False,
+                              config_extra={"room_arrange_condition": True})
+        noise = W.synth_noise(tuple(xr.shape), 0, "train_noise_arr")
+        with contextlib.redirect_stdout(io.StringIO()):
+            losses, scal = diff.diffusion.p_losses(diff._denoise, xr, tr_, noise=noise, condition=condr, condition_cross=None)
+        losses.mean().backward()
+        tag = "arrange_sep%d" % sep
+        out[tag + ".losses"] = losses.detach().numpy()
+        for k, v in scal.items():
+            out[tag + "." + k] = np.float32(v.item())
+        out[tag + ".grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
+        print(tag, "p_losses", losses.detach().numpy())
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

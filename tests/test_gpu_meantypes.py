@@ -216,3 +216,64 @@ def test_objectness_channel(golden_dir, tmp_path):
     means = plan.parts.mean(dim=0).cpu()
     params = dict(net.named_parameters())
     verify("training plan", plan.losses, {k: means[i] for i, k in enumerate(_PART_KEYS)}, lambda k: flat.grad_view(params[k]))
+
+
+@pytest.mark.parametrize("tag", ["flat", "arrange_sep1", "arrange_sep0"])
+def test_loss_layout_branches(golden_dir, tmp_path, tag):
+    """loss_separate = False on the full layout (reference diffusion_ddpm.py:597-600) and both settings on the re-arrangement layout
+    (:557-571: two logged terms, 5 diffused channels, per-token context): losses, logged terms and gradient norms of every parameter,
+    autograd path and training plan."""
+    from diffuscene_amd._lib import SS_PER_SLOT, SS_PER_TOKEN
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.train_plan import HipBackend, TrainPlan
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    arrange = tag.startswith("arrange")
+    kw, x, t, cond, _ = case_inputs("rearrange_living" if arrange else "uncond_bedroom")
+    net = Unet1D(**kw)
+    net.load_state_dict(W.synth_state_dict(kw))
+    net.to(dev())
+    cfg = dict(objectness_dim=kw.get("objectness_dim", 1), class_dim=kw.get("class_dim", 21), angle_dim=kw.get("angle_dim", 1),
+               objfeat_dim=kw.get("objfeat_dim", 0))
+    if arrange:
+        cfg["room_arrange_condition"] = True
+    diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=tag != "flat" and tag != "arrange_sep0", loss_iou=False)
+    noise = W.synth_noise(tuple(x.shape), 0, "train_noise_arr" if arrange else "train_noise")
+    names = [k for k, _ in net.named_parameters()]
+    ref = g[tag + ".grad_norms"]
+    assert len(names) == len(ref)
+    logged = sorted(k[len(tag) + 1:] for k in g.files if k.startswith(tag + ".loss."))
+    assert logged == (["loss.angle", "loss.trans"] if arrange else sorted(_PART_KEYS))
+
+    def verify(what, losses, parts, grad_of):
+        check(losses, g[tag + ".losses"], "%s p_losses (%s)" % (tag, what))
+        for k in logged:
+            want = float(g[tag + "." + k])
+            assert abs(float(parts[k]) - want) <= 1e-4 * max(1.0, abs(want)), (tag, what, k, float(parts[k]), want)
+        gn = np.array([float(grad_of(k).norm()) for k in names])
+        e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+        print("%s %s: grad-norm rel err max %.3g at %s" % (tag, what, e.max(), names[int(e.argmax())]))
+        assert e.max() < 1e-3, (tag, what, names[int(e.argmax())], e.max())
+
+    losses, scal = diff.diffusion.p_losses(diff._denoise, x.to(dev()), t.to(dev()), noise=noise.to(dev()), condition=cond.to(dev()), condition_cross=None)
+    losses.mean().backward()
+    params = dict(net.named_parameters())
+    verify("autograd path", losses, {k: v.detach() for k, v in scal.items()}, lambda k: params[k].grad)
+    for p in net.parameters():
+        p.grad = None
+    flat = FlatStorage(net)
+    B, N, C = x.shape
+    plan = TrainPlan(net, flat, diff.diffusion, B, N, SS_PER_TOKEN if arrange else SS_PER_SLOT, 512 if arrange else 128, 0, 0, HipBackend(dev()))
+    plan.x0.copy_(x.to(dev())); plan.noise.copy_(noise.to(dev())); plan.t.copy_(t.to(dev()))
+    plan.ctx_in.t.copy_(cond.reshape(B * N, 512).to(dev()) if arrange else cond[0].to(dev()))
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    torch.cuda.synchronize()
+    means = plan.parts.mean(dim=0).cpu()
+    # columns of plan.parts: the nine logged terms in _PART_KEYS order; the re-arrangement layout fills trans (1) and angle (3) (train_step.loss_step)
+    parts = {"loss.trans": means[1], "loss.angle": means[3]} if arrange else {k: means[i] for i, k in enumerate(_PART_KEYS)}
+    params = dict(net.named_parameters())
+    verify("training plan", plan.losses, parts, lambda k: flat.grad_view(params[k]))
