@@ -16,6 +16,8 @@ front of the diffusion calls.  The reference's own class is built from the refer
             (bert-base-cased is a download; SURVEY 8c: BERT features are "parity unpinned", the path is pinned from the encoder's
             last_hidden_state onwards -- the stand-in returns fake_bert_features(text))
   glove     the text config with text_glove_embedding (fc_text_f = Linear(50, 512) on ``desc_emb``)
+  fixedinst uncond with learnable_embedding false: the instance condition is fc_instance_condition(one-hot slot index) (:97-104,172-175)
+            instead of the learned positional_embedding every shipped YAML uses
 
 RNG: the reference draws t (torch.randint) and the noise (torch.randn) from torch's global CPU generator; each call below is made
 right after ``torch.manual_seed(seed)``.  The GPU tests patch torch.randint / torch.randn to draw from the same CPU generator and
@@ -42,12 +44,13 @@ from .make_golden import GOLDEN
 from .ref_loader import load_reference_package
 
 B, N, L_TEXT, SAMPLE_T, PARTIAL_P = 4, 12, 7, 20, 3
-CASES = ("uncond", "arrange", "partial", "text", "glove")
+CASES = ("uncond", "arrange", "partial", "text", "glove", "fixedinst")
 _YAML = {"uncond": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml",
          "arrange": "rearrange/diffusion_bedrooms_instancond_lat32_v_rearrange.yaml",
          "partial": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml",
          "text": "text/diffusion_bedrooms_instancond_lat32_v_bert.yaml",
-         "glove": "text/diffusion_bedrooms_instancond_lat32_v_bert.yaml"}
+         "glove": "text/diffusion_bedrooms_instancond_lat32_v_bert.yaml",
+         "fixedinst": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml"}
 SEED_LOSS, SEED_TRAIN, SEED_SAMPLE, SEED_ONE = 1234, 1235, 1236, 1237
 DELTA_PARAMS = 12
 
@@ -63,6 +66,8 @@ def network_config(case, stats_file, time_num=1000):
         cfg["net_kwargs"]["instanclass_dim"] = 128 + 64
     if case == "glove":
         cfg["text_glove_embedding"] = True
+    if case == "fixedinst":
+        cfg["learnable_embedding"] = False
     return cfg
 
 
