@@ -44,7 +44,9 @@ class FlatStorage:
         packed = {}                                     # name -> list of parameters laid out back to back
         if net is not None:
             t_blocks = [rb for rb, kind in net.resblocks_in_order() if kind == "t"]
-            c_blocks = [rb for rb, kind in net.resblocks_in_order() if kind == "c" and rb.mlp is not None]
+            # (an un-conditioned network -- context_dim + instanclass_dim = 0 -- keeps the reference's Linear(0, 1024) in its context blocks:
+            # never applied, nothing to pack; its bias stays an ordinary parameter whose gradient is never written, as in the reference)
+            c_blocks = [rb for rb, kind in net.resblocks_in_order() if kind == "c" and rb.mlp is not None and rb.mlp[1].weight.shape[1] > 0]
             packed = {"c_w": [rb.mlp[1].weight for rb in c_blocks], "c_b": [rb.mlp[1].bias for rb in c_blocks],
                       "t_w": [rb.mlp[1].weight for rb in t_blocks], "t_b": [rb.mlp[1].bias for rb in t_blocks]}
         in_pack = {id(p) for ps in packed.values() for p in ps}

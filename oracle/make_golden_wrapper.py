@@ -18,6 +18,8 @@ front of the diffusion calls.  The reference's own class is built from the refer
   glove     the text config with text_glove_embedding (fc_text_f = Linear(50, 512) on ``desc_emb``)
   fixedinst uncond with learnable_embedding false: the instance condition is fc_instance_condition(one-hot slot index) (:97-104,172-175)
             instead of the learned positional_embedding every shipped YAML uses
+  noinst    uncond with instance_condition false: NO conditioning at all (condition = None, :178-190); the context ResnetBlocks keep
+            a Linear(0, 1024) the forward never applies (denoise_net.py:166-176,190-193) and whose .grad stays None
 
 RNG: the reference draws t (torch.randint) and the noise (torch.randn) from torch's global CPU generator; each call below is made
 right after ``torch.manual_seed(seed)``.  The GPU tests patch torch.randint / torch.randn to draw from the same CPU generator and
@@ -44,13 +46,14 @@ from .make_golden import GOLDEN
 from .ref_loader import load_reference_package
 
 B, N, L_TEXT, SAMPLE_T, PARTIAL_P = 4, 12, 7, 20, 3
-CASES = ("uncond", "arrange", "partial", "text", "glove", "fixedinst")
+CASES = ("uncond", "arrange", "partial", "text", "glove", "fixedinst", "noinst")
 _YAML = {"uncond": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml",
          "arrange": "rearrange/diffusion_bedrooms_instancond_lat32_v_rearrange.yaml",
          "partial": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml",
          "text": "text/diffusion_bedrooms_instancond_lat32_v_bert.yaml",
          "glove": "text/diffusion_bedrooms_instancond_lat32_v_bert.yaml",
-         "fixedinst": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml"}
+         "fixedinst": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml",
+         "noinst": "uncond/diffusion_bedrooms_instancond_lat32_v.yaml"}
 SEED_LOSS, SEED_TRAIN, SEED_SAMPLE, SEED_ONE = 1234, 1235, 1236, 1237
 DELTA_PARAMS = 12
 
@@ -68,6 +71,9 @@ def network_config(case, stats_file, time_num=1000):
         cfg["text_glove_embedding"] = True
     if case == "fixedinst":
         cfg["learnable_embedding"] = False
+    if case == "noinst":
+        cfg["instance_condition"] = False
+        cfg["net_kwargs"]["instanclass_dim"] = 0
     return cfg
 
 
@@ -104,7 +110,9 @@ def wrapper_state_dict(module):
     parameters -- positional_embedding, fc_text_f, fc_partial_condition, fc_arrange_condition -- by name)."""
     sd = {}
     for k, v in module.state_dict().items():
-        if k == "positional_embedding":
+        if v.numel() == 0:                          # the Linear(0, 1024) of an un-conditioned context block
+            sd[k] = torch.zeros(tuple(v.shape))
+        elif k == "positional_embedding":
             sd[k] = W.synth_noise(tuple(v.shape), 90, "wrapper_positional_embedding")
         else:
             sd[k] = W.synth_tensor(k[len("diffusion.model."):] if k.startswith("diffusion.model.") else k, tuple(v.shape), 0)
@@ -170,7 +178,7 @@ def main():
         inner = m.diffusion.get_loss_iter
 
         def spy(data, noises=None, condition=None, condition_cross=None):
-            seen.update(target=data.detach().clone(), condition=condition.detach().clone(),
+            seen.update(target=data.detach().clone(), condition=None if condition is None else condition.detach().clone(),
                         cross=None if condition_cross is None else condition_cross.detach().clone())
             return inner(data, noises=noises, condition=condition, condition_cross=condition_cross)
         m.diffusion.get_loss_iter = spy
@@ -178,7 +186,8 @@ def main():
         loss, parts = m.get_loss(s)
         m.diffusion.get_loss_iter = inner
         out[case + ".target"] = seen["target"].numpy()
-        out[case + ".condition"] = seen["condition"].numpy()
+        if seen["condition"] is not None:
+            out[case + ".condition"] = seen["condition"].numpy()
         if seen["cross"] is not None:
             out[case + ".cross"] = seen["cross"].numpy()
         out[case + ".loss"] = np.float32(loss.item())
@@ -197,9 +206,9 @@ def main():
         logger.clear()
         params = dict(m.named_parameters())
         out[case + ".train.delta_norms"] = np.array([float((params[k].detach() - before[k]).norm()) for k in names], dtype=np.float32)
-        out[case + ".train.grad_norms"] = np.array([float(params[k].grad.norm()) for k in names], dtype=np.float32)
+        out[case + ".train.grad_norms"] = np.array([0.0 if params[k].grad is None else float(params[k].grad.norm()) for k in names], dtype=np.float32)
         print("%-8s loss %.6f  train %.6f  gradnorm %.4f  target %s condition %s" % (
-            case, out[case + ".loss"], ret, out[case + ".train.gradnorm"], tuple(seen["target"].shape), tuple(seen["condition"].shape)))
+            case, out[case + ".loss"], ret, out[case + ".train.gradnorm"], tuple(seen["target"].shape), None if seen["condition"] is None else tuple(seen["condition"].shape)))
 
         # ---- sampling (T = 20): raw samples at B = 4, post-filtered dicts at batch_size 1 -------------------------------------------
         mod, m, cfg = build_reference_wrapper(case, stats_file, time_num=SAMPLE_T)
