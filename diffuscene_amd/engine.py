@@ -19,7 +19,8 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, SS_BY_INDEX, SS_NONE, SS_PER_SCE
 
 D = 512
 HID = 128
-DEC_PAD = 32        # rows per head of the stacked, zero-padded decoder output projections (bbox 8, class <= 32, objfeat 32)
+DEC_PAD = 32        # rows per head of the stacked, zero-padded decoder output projections (bbox 8, class <= 32, objfeat 32); a wider head
+                    # (objfeat_dim = 64) raises the engine's dec_pad to the next multiple
 
 
 class _Pool:
@@ -364,12 +365,13 @@ class Plan:
             # layer 3: the narrow output projections (8 / 25 / 32 columns) as ONE batched launch on weights zero-padded to DEC_PAD rows
             # per head, into a padded [M, Hd * DEC_PAD] buffer, then one gather into the heads' columns of the (M, C) output (round 4:
             # three launches of 25-28 us for 0.05 % of the flops; the products of the valid rows are unchanged: same kernel, same tile)
-            pad = pool.get(M, Hd * DEC_PAD)
-            self.gemm_batched(d2[:, :D], e.dec_w3p[:DEC_PAD], pad[:, :DEC_PAD], e.dec_b3p[:DEC_PAD], Hd, D, DEC_PAD * D, DEC_PAD, DEC_PAD)
+            P = e.dec_pad
+            pad = pool.get(M, Hd * P)
+            self.gemm_batched(d2[:, :D], e.dec_w3p[:P], pad[:, :P], e.dec_b3p[:P], Hd, D, P * D, P, P)
             spans = (_lib.ColSpan * Hd)()
             col = 0
             for i, (seq, width) in enumerate(e.dec_heads):
-                spans[i].src_col, spans[i].dst_col, spans[i].width = i * DEC_PAD, col, width
+                spans[i].src_col, spans[i].dst_col, spans[i].width = i * P, col, width
                 col += width
             self.call("dsc_gather_columns_f32", self.out.data_ptr(), self.out.stride(0), pad.data_ptr(), pad.stride(0), M, spans, Hd,
                       keep=(spans, pad))
@@ -451,9 +453,9 @@ class DenoiserEngine:
             self.dec_b1 = torch.empty((Hd * 2 * D,), device=device)
             self.dec_w2 = torch.empty((Hd * D, 2 * D), device=device)
             self.dec_b2 = torch.empty((Hd * D,), device=device)
-            assert all(width <= DEC_PAD for _, width in self.dec_heads)
-            self.dec_w3p = torch.zeros((Hd * DEC_PAD, D), device=device)      # output projections, zero-padded to DEC_PAD rows each
-            self.dec_b3p = torch.zeros((Hd * DEC_PAD,), device=device)
+            self.dec_pad = DEC_PAD * ((max(width for _, width in self.dec_heads) + DEC_PAD - 1) // DEC_PAD)
+            self.dec_w3p = torch.zeros((Hd * self.dec_pad, D), device=device)      # output projections, zero-padded to dec_pad rows each
+            self.dec_b3p = torch.zeros((Hd * self.dec_pad,), device=device)
 
     def planes_of(self, w):
         """bf16 planes (3, n, K) of a weight the plans multiply with (None where the split path does not apply).  The entry is
@@ -509,8 +511,8 @@ class DenoiserEngine:
                     self.dec_b1[i * H2:(i + 1) * H2].copy_(seq[0].bias)
                     self.dec_w2[i * D:(i + 1) * D].copy_(seq[2].weight.view(D, H2))
                     self.dec_b2[i * D:(i + 1) * D].copy_(seq[2].bias)
-                    self.dec_w3p[i * DEC_PAD:i * DEC_PAD + width].copy_(seq[4].weight.view(width, D))
-                    self.dec_b3p[i * DEC_PAD:i * DEC_PAD + width].copy_(seq[4].bias)
+                    self.dec_w3p[i * self.dec_pad:i * self.dec_pad + width].copy_(seq[4].weight.view(width, D))
+                    self.dec_b3p[i * self.dec_pad:i * self.dec_pad + width].copy_(seq[4].bias)
             if self._planes:
                 ops.split_planes([(w2, planes, False) for w2, planes in self._planes.values()])
         self.sig = sig

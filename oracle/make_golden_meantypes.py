@@ -138,6 +138,27 @@ def main():
             out[tag + "." + k] = np.float32(v.item())
         out[tag + ".grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
         print(tag, "p_losses", losses.detach().numpy())
+    # objfeat_dim = 64 (the datasets carry a 32-d and a 64-d shape code, threed_front_dataset.py:481-513; every shipped YAML diffuses the 32-d one,
+    # the wrapper reads sample_params["objfeats"] for any other width, diffusion_scene_layout_ddpm.py:139-143): 94 channels
+    kw64 = dict(kw, objfeat_dim=64, channels=8 + kw["class_dim"] + 64)
+    x64 = W.synth_scene_batch(B, N, kw["class_dim"], 64, seed=0)
+    net, diff = build_ref(kw64, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=stats_file)
+    with torch.no_grad():
+        out["objfeat64.forward"] = net(x64, t, cond, None).numpy()
+    noise = W.synth_noise(tuple(x64.shape), 0, "train_noise_64")
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses, scal = diff.diffusion.p_losses(diff._denoise, x64, t, noise=noise, condition=cond, condition_cross=None)
+    losses.mean().backward()
+    out["objfeat64.losses"] = losses.detach().numpy()
+    for k, v in scal.items():
+        out["objfeat64." + k] = np.float32(v.item())
+    out["objfeat64.grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
+    net, diff = build_ref(kw64, time_num=20, model_mean_type="v")
+    seq = noise_list([(B, N, 94)] * 21, 14, "mt_64_")
+    with torch.no_grad():
+        s = diff.gen_samples((B, N, 94), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=True)
+    out["objfeat64.T20"] = s.numpy()
+    print("objfeat64 p_losses", losses.detach().numpy(), "chain", float(s.abs().mean()))
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

@@ -277,3 +277,70 @@ def test_loss_layout_branches(golden_dir, tmp_path, tag):
     parts = {"loss.trans": means[1], "loss.angle": means[3]} if arrange else {k: means[i] for i, k in enumerate(_PART_KEYS)}
     params = dict(net.named_parameters())
     verify("training plan", plan.losses, parts, lambda k: flat.grad_view(params[k]))
+
+
+def test_objfeat_dim_64(golden_dir, tmp_path):
+    """objfeat_dim = 64 (94 channels; the wider latent code the datasets also carry, read from sample_params["objfeats"]): forward,
+    p_losses through both training paths, a T = 20 chain eager and from the hipGraph.  The decoder's stacked output projection pads
+    its heads to 64 rows for this network (engine.dec_pad) instead of 32."""
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.sampler import NoiseReplay
+    from diffuscene_amd.train_plan import HipBackend, TrainPlan
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    nc = kw["class_dim"]
+    kw64 = dict(kw, objfeat_dim=64, channels=8 + nc + 64)
+    B, N = x.shape[:2]
+    x64 = W.synth_scene_batch(B, N, nc, 64, seed=0)
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    net = Unet1D(**kw64)
+    net.load_state_dict(W.synth_state_dict(kw64))
+    net.to(dev())
+    cfg = dict(objectness_dim=0, class_dim=nc, angle_dim=2, objfeat_dim=64)
+    diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=str(stats))
+    with torch.no_grad():
+        check(net(x64.to(dev()), t.to(dev()), cond.to(dev()), None), g["objfeat64.forward"], "objfeat64 forward")
+    assert net.engine(dev()).dec_pad == 64
+    noise = W.synth_noise(tuple(x64.shape), 0, "train_noise_64")
+    names = [k for k, _ in net.named_parameters()]
+    ref = g["objfeat64.grad_norms"]
+
+    def verify(what, losses, parts, grad_of):
+        check(losses, g["objfeat64.losses"], "objfeat64 p_losses (%s)" % what)
+        for k in _PART_KEYS:
+            want = float(g["objfeat64." + k])
+            assert abs(float(parts[k]) - want) <= 1e-4 * max(1.0, abs(want)), (what, k, float(parts[k]), want)
+        gn = np.array([float(grad_of(k).norm()) for k in names])
+        e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+        print("objfeat64 %s: grad-norm rel err max %.3g at %s" % (what, e.max(), names[int(e.argmax())]))
+        assert e.max() < 1e-3, (what, names[int(e.argmax())], e.max())
+
+    losses, scal = diff.diffusion.p_losses(diff._denoise, x64.to(dev()), t.to(dev()), noise=noise.to(dev()), condition=cond.to(dev()), condition_cross=None)
+    losses.mean().backward()
+    params = dict(net.named_parameters())
+    verify("autograd path", losses, {k: v.detach() for k, v in scal.items()}, lambda k: params[k].grad)
+    for p in net.parameters():
+        p.grad = None
+    flat = FlatStorage(net)
+    plan = TrainPlan(net, flat, diff.diffusion, B, N, SS_PER_SLOT, 128, 0, 0, HipBackend(dev()))
+    plan.x0.copy_(x64.to(dev())); plan.noise.copy_(noise.to(dev())); plan.t.copy_(t.to(dev()))
+    plan.ctx_in.t.copy_(cond[0].to(dev()))
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    torch.cuda.synchronize()
+    means = plan.parts.mean(dim=0).cpu()
+    params = dict(net.named_parameters())
+    verify("training plan", plan.losses, {k: means[i] for i, k in enumerate(_PART_KEYS)}, lambda k: flat.grad_view(params[k]))
+    diff20 = DiffusionPoint(net, cfg, time_num=20, model_mean_type="v")
+    seq = torch.stack(noise_list([(B, N, 94)] * 21, 14, "mt_64_")).to(dev())
+    with torch.no_grad():
+        eager = diff20.gen_samples((B, N, 94), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=False)
+        graph = diff20.gen_samples((B, N, 94), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=True)
+    assert torch.equal(eager, graph)
+    check(eager, g["objfeat64.T20"], "objfeat64 T=20 chain")
