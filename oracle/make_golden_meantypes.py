@@ -159,6 +159,29 @@ def main():
         s = diff.gen_samples((B, N, 94), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=True)
     out["objfeat64.T20"] = s.numpy()
     print("objfeat64 p_losses", losses.detach().numpy(), "chain", float(s.abs().mean()))
+    # the constructor DEFAULTS of the reference (Unet1D / GaussianDiffusion: objectness_dim 1, class_dim 21, angle_dim 1, objfeat_dim 0 --
+    # the layout of the encodings without a shape code and with a raw angle, bbox_dim 7): 29 channels
+    kwl = dict(kw, objectness_dim=1, class_dim=21, angle_dim=1, objfeat_dim=0, channels=7 + 21 + 1)
+    base = W.synth_scene_batch(B, N, 21, 0, seed=0)                       # [trans 3 | size 3 | cos | sin | class 21]
+    xl = torch.cat([base[:, :, :6], torch.atan2(base[:, :, 7:8], base[:, :, 6:7]) / np.pi, base[:, :, 8:29],
+                    torch.where(base[:, :, 28:29] > 0, -1.0, 1.0)], dim=-1).contiguous()
+    net, diff = build_ref(kwl, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=stats_file)
+    with torch.no_grad():
+        out["legacy.forward"] = net(xl, t, cond, None).numpy()
+    noise = W.synth_noise(tuple(xl.shape), 0, "train_noise_legacy")
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses, scal = diff.diffusion.p_losses(diff._denoise, xl, t, noise=noise, condition=cond, condition_cross=None)
+    losses.mean().backward()
+    out["legacy.losses"] = losses.detach().numpy()
+    for k, v in scal.items():
+        out["legacy." + k] = np.float32(v.item())
+    out["legacy.grad_norms"] = np.array([float(p.grad.norm()) for _, p in net.named_parameters()], dtype=np.float32)
+    net, diff = build_ref(kwl, time_num=20, model_mean_type="v")
+    seq = noise_list([(B, N, 29)] * 21, 15, "mt_legacy_")
+    with torch.no_grad():
+        s = diff.gen_samples((B, N, 29), "cpu", condition=cond, condition_cross=None, noise_fn=Replay(seq), clip_denoised=True)
+    out["legacy.T20"] = s.numpy()
+    print("legacy p_losses", losses.detach().numpy(), {k: round(float(v), 5) for k, v in scal.items()}, "chain", float(s.abs().mean()))
     np.savez_compressed(os.path.join(GOLDEN, "meantypes.npz"), **out)
     print("written", os.path.join(GOLDEN, "meantypes.npz"))
 

@@ -344,3 +344,70 @@ def test_objfeat_dim_64(golden_dir, tmp_path):
         graph = diff20.gen_samples((B, N, 94), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=True)
     assert torch.equal(eager, graph)
     check(eager, g["objfeat64.T20"], "objfeat64 T=20 chain")
+
+
+def test_reference_default_layout(golden_dir, tmp_path):
+    """The constructor defaults of the reference (objectness_dim 1, class_dim 21, angle_dim 1 -- a raw angle, bbox_dim 7 --, no shape code:
+    29 channels): forward, p_losses with the IoU term through both training paths, a T = 20 chain eager and from the hipGraph."""
+    from diffuscene_amd._lib import SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.sampler import NoiseReplay
+    from diffuscene_amd.train_plan import HipBackend, TrainPlan
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    kw, x, t, cond, _ = case_inputs("uncond_bedroom")
+    B, N = x.shape[:2]
+    kwl = dict(kw, objectness_dim=1, class_dim=21, angle_dim=1, objfeat_dim=0, channels=29)
+    base = W.synth_scene_batch(B, N, 21, 0, seed=0)
+    xl = torch.cat([base[:, :, :6], torch.atan2(base[:, :, 7:8], base[:, :, 6:7]) / np.pi, base[:, :, 8:29],
+                    torch.where(base[:, :, 28:29] > 0, -1.0, 1.0)], dim=-1).contiguous()
+    stats = tmp_path / "dataset_stats.txt"
+    stats.write_text(json.dumps(W.DATASET_STATS))
+    net = Unet1D(**kwl)
+    net.load_state_dict(W.synth_state_dict(kwl))
+    net.to(dev())
+    cfg = dict(objectness_dim=1, class_dim=21, angle_dim=1, objfeat_dim=0)
+    diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type="v", loss_separate=True, loss_iou=True, train_stats_file=str(stats))
+    with torch.no_grad():
+        check(net(xl.to(dev()), t.to(dev()), cond.to(dev()), None), g["legacy.forward"], "default-layout forward")
+    noise = W.synth_noise(tuple(xl.shape), 0, "train_noise_legacy")
+    names = [k for k, _ in net.named_parameters()]
+    ref = g["legacy.grad_norms"]
+    assert len(names) == len(ref)
+
+    def verify(what, losses, parts, grad_of):
+        check(losses, g["legacy.losses"], "default-layout p_losses (%s)" % what)
+        for k in _PART_KEYS:
+            want = float(g["legacy." + k])
+            assert abs(float(parts[k]) - want) <= 1e-4 * max(1.0, abs(want)), (what, k, float(parts[k]), want)
+        gn = np.array([float(grad_of(k).norm()) for k in names])
+        e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+        print("default layout %s: grad-norm rel err max %.3g at %s" % (what, e.max(), names[int(e.argmax())]))
+        assert e.max() < 1e-3, (what, names[int(e.argmax())], e.max())
+
+    losses, scal = diff.diffusion.p_losses(diff._denoise, xl.to(dev()), t.to(dev()), noise=noise.to(dev()), condition=cond.to(dev()), condition_cross=None)
+    losses.mean().backward()
+    params = dict(net.named_parameters())
+    verify("autograd path", losses, {k: v.detach() for k, v in scal.items()}, lambda k: params[k].grad)
+    for p in net.parameters():
+        p.grad = None
+    flat = FlatStorage(net)
+    plan = TrainPlan(net, flat, diff.diffusion, B, N, SS_PER_SLOT, 128, 0, 0, HipBackend(dev()))
+    plan.x0.copy_(xl.to(dev())); plan.noise.copy_(noise.to(dev())); plan.t.copy_(t.to(dev()))
+    plan.ctx_in.t.copy_(cond[0].to(dev()))
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    torch.cuda.synchronize()
+    means = plan.parts.mean(dim=0).cpu()
+    params = dict(net.named_parameters())
+    verify("training plan", plan.losses, {k: means[i] for i, k in enumerate(_PART_KEYS)}, lambda k: flat.grad_view(params[k]))
+    diff20 = DiffusionPoint(net, cfg, time_num=20, model_mean_type="v")
+    seq = torch.stack(noise_list([(B, N, 29)] * 21, 15, "mt_legacy_")).to(dev())
+    with torch.no_grad():
+        eager = diff20.gen_samples((B, N, 29), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=False)
+        graph = diff20.gen_samples((B, N, 29), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(seq), clip_denoised=True, graph=True)
+    assert torch.equal(eager, graph)
+    check(eager, g["legacy.T20"], "default-layout T=20 chain")
