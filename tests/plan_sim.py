@@ -223,9 +223,12 @@ class SimBackend:
                 liou = torch.zeros(B, dtype=torch.float64)
                 iou_avg = torch.zeros(B, dtype=torch.float64)
                 if iou:
-                    A = ca.double()[t].view(-1, 1, 1)
-                    Bc = cb.double()[t].view(-1, 1, 1)
-                    xr = {0: A * xt - Bc * o, 1: o, 2: A * xt - Bc * o}[mean_type].clamp(-1.0, 1.0)
+                    if ca is None:                       # 'x0': the network output IS the reconstruction, no coefficient tables
+                        xr = o.clamp(-1.0, 1.0)
+                    else:
+                        A = ca.double()[t].view(-1, 1, 1)
+                        Bc = cb.double()[t].view(-1, 1, 1)
+                        xr = (A * xt - Bc * o).clamp(-1.0, 1.0)
                     if no > 0:
                         valid = (xr[:, :, bb + nc:bb + nc + no] >= 0).double().squeeze(2)
                     else:

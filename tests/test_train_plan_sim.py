@@ -204,3 +204,81 @@ def test_plan_at_the_full_text_batch_matches_the_reference_golden(tmp_path, gold
     ref = g["text.grad_norms"]
     assert (np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())).max() < 1e-4
     assert abs(float(plan.d_cross.norm()) - float(g["text.d_cross_norm"])) <= 1e-4 * float(g["text.d_cross_norm"])
+
+
+@pytest.mark.parametrize("variant", ["eps", "x0", "objectness", "objfeat64", "legacy", "flat", "arrange_sep0", "arrange_sep1"])
+def test_plan_variants_match_the_reference_goldens(variant, tmp_path, golden_dir):
+    """The layouts and loss branches no shipped `_v` YAML reaches ('eps' / 'x0' targets, an objectness channel, the 64-d shape code,
+    the reference's constructor defaults, loss_separate = False, the re-arrangement loss) -- the plan on the torch backend against
+    outputs of the REAL reference (tests/golden/meantypes.npz, oracle/make_golden_meantypes.py): per-scene losses, logged terms and
+    the gradient norm of every parameter.  tests/test_gpu_meantypes.py holds the HIP backend to the same file."""
+    import contextlib
+    import io
+    import numpy as np
+    from plan_sim import SimBackend
+    from diffuscene_amd._lib import SS_PER_SLOT, SS_PER_TOKEN
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    from diffuscene_amd.networks.diffusion_ddpm import DiffusionPoint
+    from diffuscene_amd.train_plan import TrainPlan
+    from oracle.make_golden import case_inputs
+    g = np.load(os.path.join(golden_dir, "meantypes.npz"))
+    arrange = variant.startswith("arrange")
+    kw, x, t, cond, _ = case_inputs("rearrange_living" if arrange else "uncond_bedroom")
+    B, N = x.shape[:2]
+    nc = kw.get("class_dim", 21)
+    cfg = dict(objectness_dim=kw.get("objectness_dim", 1), class_dim=nc, angle_dim=kw.get("angle_dim", 1), objfeat_dim=kw.get("objfeat_dim", 0))
+    mean_type, separate, iou, noise_tag = "v", True, not arrange, "train_noise_arr" if arrange else "train_noise"
+    if variant in ("eps", "x0"):
+        mean_type = variant
+    elif variant == "objectness":
+        kw = dict(kw, objectness_dim=1, channels=kw["channels"] + 1)
+        x = torch.cat([x[:, :, :8 + nc], torch.where(x[:, :, 8 + nc - 1:8 + nc] > 0, -1.0, 1.0), x[:, :, 8 + nc:]], dim=-1).contiguous()
+        cfg["objectness_dim"], noise_tag = 1, "train_noise_obj"
+    elif variant == "objfeat64":
+        kw = dict(kw, objfeat_dim=64, channels=8 + nc + 64)
+        x = W.synth_scene_batch(B, N, nc, 64, seed=0)
+        cfg["objfeat_dim"], noise_tag = 64, "train_noise_64"
+    elif variant == "legacy":
+        kw = dict(kw, objectness_dim=1, class_dim=21, angle_dim=1, objfeat_dim=0, channels=29)
+        base = W.synth_scene_batch(B, N, 21, 0, seed=0)
+        x = torch.cat([base[:, :, :6], torch.atan2(base[:, :, 7:8], base[:, :, 6:7]) / np.pi, base[:, :, 8:29],
+                       torch.where(base[:, :, 28:29] > 0, -1.0, 1.0)], dim=-1).contiguous()
+        cfg, noise_tag = dict(objectness_dim=1, class_dim=21, angle_dim=1, objfeat_dim=0), "train_noise_legacy"
+    elif variant == "flat":
+        separate, iou = False, False
+    elif arrange:
+        cfg["room_arrange_condition"] = True
+        separate = variant.endswith("1")
+    stats = os.path.join(str(tmp_path), "dataset_stats.txt")
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = Unet1D(**kw)
+        net.load_state_dict(W.synth_state_dict(kw))
+        diff = DiffusionPoint(net, cfg, time_num=1000, model_mean_type=mean_type, loss_separate=separate, loss_iou=iou,
+                              train_stats_file=stats if iou else None).diffusion
+    noise = W.synth_noise(tuple(x.shape), 0, noise_tag)
+    flat = FlatStorage(net)
+    tb = {n: getattr(diff, n).float() for n in diff._TABLE_NAMES}
+    plan = TrainPlan(net, flat, diff, B, N, SS_PER_TOKEN if arrange else SS_PER_SLOT, 512 if arrange else 128, 0, 0, SimBackend(), tables=tb)
+    plan.x0.copy_(x); plan.noise.copy_(noise); plan.t.copy_(t)
+    plan.ctx_in.t.copy_(cond.reshape(B * N, 512) if arrange else cond[0])
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    assert _rel(plan.losses, torch.from_numpy(g[variant + ".losses"])) < 2e-6
+    keys = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class', 'loss.object', 'loss.objfeat', 'loss.liou', 'loss.bbox_iou')
+    means = plan.parts.mean(dim=0)
+    parts = {"loss.trans": means[1], "loss.angle": means[3]} if arrange else {k: means[i] for i, k in enumerate(keys)}
+    for k, v in parts.items():
+        want = float(g[variant + "." + k])
+        assert abs(float(v) - want) <= 1e-5 * max(1.0, abs(want)), (variant, k, float(v), want)
+    names = [k for k, _ in net.named_parameters()]
+    params = dict(net.named_parameters())
+    gn = np.array([float(flat.grad_view(params[k]).norm()) for k in names])
+    ref = g[variant + ".grad_norms"]
+    assert len(ref) == len(gn)
+    e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
+    assert e.max() < 1e-3, (variant, names[int(e.argmax())], float(e.max()))
