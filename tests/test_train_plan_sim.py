@@ -282,3 +282,61 @@ def test_plan_variants_match_the_reference_goldens(variant, tmp_path, golden_dir
     assert len(ref) == len(gn)
     e = np.abs(gn - ref) / np.maximum(ref, 1e-3 * ref.max())
     assert e.max() < 1e-3, (variant, names[int(e.argmax())], float(e.max()))
+
+
+@pytest.mark.parametrize("case", ["noinst", "uncond"])
+def test_wrapper_step_on_the_plan_matches_the_reference_wrapper_golden(case, tmp_path, golden_dir):
+    """One ``get_loss`` of the REAL reference wrapper (tests/golden/wrapper.npz) reproduced on the CPU: OUR wrapper assembles the batch
+    (``_loss_inputs``), the seeded generator gives t and the noise in the reference's order, the static plan runs on the torch backend.
+    'noinst' is the un-conditioned network (condition None -> SS_NONE, a never-applied Linear(0, 1024) in every context block),
+    'uncond' conditions on the learned positional embedding read in place.  (The fc_instance_condition variant needs the HIP ops of the
+    wrapper-level MLP: tests/test_gpu_wrapper.py.)"""
+    import contextlib
+    import io
+    import numpy as np
+    from plan_sim import SimBackend
+    from diffuscene_amd._lib import SS_NONE, SS_PER_SLOT
+    from diffuscene_amd.flat import FlatStorage
+    from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
+    from diffuscene_amd.train_plan import TrainPlan
+    from oracle.make_golden_wrapper import SEED_LOSS, network_config, wrapper_batch, wrapper_state_dict
+    g = np.load(os.path.join(golden_dir, "wrapper.npz"))
+    stats = os.path.join(str(tmp_path), "dataset_stats.txt")
+    with open(stats, "w") as f:
+        json.dump(W.DATASET_STATS, f)
+    cfg = network_config(case, stats)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DiffusionSceneLayout_DDPM(cfg["class_dim"] + 1, None, cfg)
+    m.load_state_dict(wrapper_state_dict(m))
+    s, _ = wrapper_batch(case)
+    with torch.no_grad():
+        target, condition, cross = m._loss_inputs(s)
+    assert cross is None and torch.equal(target, torch.from_numpy(g[case + ".target"]))
+    assert (condition is None) == (case == "noinst")
+    B, N, C = target.shape
+    torch.manual_seed(SEED_LOSS)                         # the reference's draws: t (get_loss_iter), then the noise (p_losses)
+    t = torch.randint(0, 1000, size=(B,))
+    noise = torch.randn(target.shape)
+    net, diff = m.diffusion.model, m.diffusion.diffusion
+    flat = FlatStorage(m)
+    tb = {n: getattr(diff, n).float() for n in diff._TABLE_NAMES}
+    plan = TrainPlan(net, flat, diff, B, N, SS_NONE if condition is None else SS_PER_SLOT, 0 if condition is None else condition.shape[-1],
+                     0, 0, SimBackend(), tables=tb, ctx_param=m.positional_embedding if case == "uncond" else None)
+    plan.x0.copy_(target); plan.noise.copy_(noise); plan.t.copy_(t)
+    flat.G.fill_(float("nan"))
+    flat.zero_head()
+    plan.run_forward()
+    plan.run_backward()
+    want = float(g[case + ".loss"])
+    assert abs(float(plan.losses.mean()) - want) <= 2e-6 * abs(want), (case, float(plan.losses.mean()), want)
+    keys = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class', 'loss.object', 'loss.objfeat', 'loss.liou', 'loss.bbox_iou')
+    means = plan.parts.mean(dim=0)
+    for i, k in enumerate(keys):
+        w = float(g[case + ".part." + k])
+        assert abs(float(means[i]) - w) <= 1e-5 * max(1.0, abs(w)), (case, k, float(means[i]), w)
+    # every gradient of the denoiser the plan owns was written (the never-applied context Linear of 'noinst' is not the plan's: it
+    # stays untouched, as its .grad stays None in the reference)
+    never_applied = {id(q) for rb, kind in net.resblocks_in_order() if kind == "c" and case == "noinst" for q in rb.mlp[1].parameters()}
+    for name, p in net.named_parameters():
+        if p.numel() and id(p) not in never_applied:
+            assert torch.isfinite(flat.grad_view(p)).all(), name
