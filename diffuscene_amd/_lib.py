@@ -16,6 +16,7 @@ if os.environ.get("DSC_HIP_LIB"):
 ACT_NONE, ACT_GELU, ACT_SILU, ACT_LEAKY01 = 0, 1, 2, 3
 SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
 MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
+TILE_GN_80_W8, TILE_GN_80_W4, TILE_160x256, TILE_160x128_W4 = 1, 2, 5, 8      # DSC_TILE_* (dsc_gemm_split_tile)
 WS_MAX = 64
 MAX_TOKENS_PER_SCENE = 160
 
@@ -46,6 +47,7 @@ class GemmArgs(C.Structure):
         ("ss_index", C.c_void_p),
         ("w_planes", C.c_void_p),
         ("actgrad_x", C.c_void_p), ("ld_actgrad", C.c_int64),
+        ("ss_rows", C.c_int32),
     ]
 
 
@@ -97,6 +99,7 @@ SIGNATURES = {
     "dsc_gemm_gn_silu_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "dsc_split_bf16x3_f32": (C.c_int, [C.POINTER(SplitItem), C.c_int32, C.c_void_p]),
     "dsc_gemm_arithmetic": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
+    "dsc_gemm_split_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
     "dsc_get_gemm_arithmetic": (C.c_int, []),
     "dsc_set_gemm_arithmetic": (C.c_int, [C.c_int32]),
     "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
@@ -114,10 +117,11 @@ SIGNATURES = {
                                     C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "dsc_time_embedding_f32": (C.c_int, [c_i64p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
     "dsc_activation_f32": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
-    "dsc_q_sample_f32": (C.c_int, [c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int64,
+    "dsc_q_sample_f32": (C.c_int, [c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int64, C.c_int32,
                                    C.c_void_p]),
     "dsc_p_sample_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                   c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+                                   c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "dsc_device_error_count": (C.c_int64, [C.c_int32]),
     "dsc_add_scalar_i64": (C.c_int, [c_i64p, C.c_int32, C.c_int64, C.c_void_p]),
     "dsc_knn16_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "dsc_rowsq_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int64, c_f32p, C.c_void_p]),
@@ -175,14 +179,14 @@ SIGNATURES = {
     "dsc_adam_step_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     c_f32p, C.c_void_p]),
     "dsc_ddpm_loss_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float),
-                                    c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_float, C.c_void_p]),
+                                    c_f32p, c_f32p, c_f32p] + [C.c_int32] * 12 + [C.c_float, C.c_int32, C.c_void_p]),
     "dsc_copy2d_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_add2d_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_activation_bwd_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
     "dsc_transpose_batched_f32": (C.c_int, [C.POINTER(WsItem), C.c_int32, C.c_void_p]),
     "dsc_transpose_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_complete_overwrite_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, C.c_int32, C.c_int32,
-                                             C.c_int32, C.c_int32, C.c_void_p]),
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }
 
 _lib = None
@@ -233,6 +237,15 @@ def set_gemm_arithmetic(name):
     prev = "split" if split_enabled() else "f32"
     check(load().dsc_set_gemm_arithmetic(1 if name == "split" else 0), "dsc_set_gemm_arithmetic")
     return prev
+
+
+def device_error_count(reset=False):
+    """Out-of-range device timesteps the DDPM kernels clamped since the last reset (dsc_device_error_count; synchronises).  0 in a
+    correct run: tests assert it, debugging sessions read it."""
+    n = load().dsc_device_error_count(1 if reset else 0)
+    if n < 0:
+        raise RuntimeError("dsc_device_error_count failed (HIP error)")
+    return int(n)
 
 
 def check(rc, what):

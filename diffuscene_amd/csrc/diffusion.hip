@@ -2,6 +2,7 @@
 // write of the result, coefficient gathers from device-resident tables.  Compiled with -ffp-contract=off:
 // the reference evaluates  a*x + b*y  as two rounded products and a rounded sum; we do exactly that, so the
 // results are bit-identical to the fp32 CPU path on the same inputs.
+#define DSC_BAD_INDEX_COUNTER
 #include "dsc_common.h"
 
 namespace {
@@ -9,9 +10,9 @@ namespace {
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
                                                       const int64_t* __restrict__ t, const float* __restrict__ sa,
                                                       const float* __restrict__ sb, float* __restrict__ xt,
-                                                      float* __restrict__ vout, int64_t inner) {
+                                                      float* __restrict__ vout, int64_t inner, int T) {
     const int b = blockIdx.y;
-    const int64_t tv = t[b];
+    const int64_t tv = dsc_checked_index(t[b], T);
     const float a = sa[tv], s = sb[tv];
     const int64_t base = (int64_t)b * inner;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (int64_t)gridDim.x * blockDim.x) {
@@ -30,9 +31,9 @@ __global__ __launch_bounds__(256) void p_sample_kernel(const float* xt, const fl
                                                       const float* __restrict__ ca, const float* __restrict__ cb,
                                                       const float* __restrict__ c1, const float* __restrict__ c2,
                                                       const float* __restrict__ sigma, float* out,   // out may alias xt (in-place step)
-                                                      float* __restrict__ x0_out, int mean_type, int clip, int64_t inner) {
+                                                      float* __restrict__ x0_out, int mean_type, int clip, int64_t inner, int T) {
     const int b = blockIdx.y;
-    const int64_t tv = t[b];
+    const int64_t tv = dsc_checked_index(t[b], T);
     const float A = (mean_type == DSC_MEAN_X0) ? 0.f : ca[tv];
     const float Bc = (mean_type == DSC_MEAN_X0) ? 0.f : cb[tv];
     const float k1 = c1[tv], k2 = c2[tv];
@@ -60,9 +61,9 @@ __global__ void add_scalar_i64_kernel(int64_t* t, int count, int64_t delta) {
 __global__ __launch_bounds__(256) void complete_overwrite_kernel(float* __restrict__ x, const float* __restrict__ partial,
                                                                 const float* __restrict__ noise,
                                                                 const int64_t* __restrict__ t, const float* __restrict__ sa,
-                                                                const float* __restrict__ sb, int n, int p, int c) {
+                                                                const float* __restrict__ sb, int n, int p, int c, int T) {
     const int b = blockIdx.y;
-    const int64_t tv = t[b];
+    const int64_t tv = dsc_checked_index(t[b], T);
     const float a = sa[tv], s = sb[tv];
     const int64_t cnt = (int64_t)p * c;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
@@ -114,11 +115,11 @@ inline unsigned grid_x(int64_t inner) {
 
 extern "C" int dsc_q_sample_f32(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
                                 const float* sqrt_1mac, float* x_t, float* v_out, int32_t b, int64_t inner,
-                                dsc_stream_t stream) {
-    if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t || b < 1 || inner < 1) return DSC_EINVAL;
+                                int32_t num_timesteps, dsc_stream_t stream) {
+    if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !x_t || b < 1 || inner < 1 || num_timesteps < 1) return DSC_EINVAL;
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(q_sample_kernel, dim3(grid_x(inner), b), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x0, noise, t, sqrt_ac, sqrt_1mac, x_t, v_out, inner);
+                       x0, noise, t, sqrt_ac, sqrt_1mac, x_t, v_out, inner, num_timesteps);
     DSC_LAUNCH_CHECK();
     return 0;
 }
@@ -126,13 +127,14 @@ extern "C" int dsc_q_sample_f32(const float* x0, const float* noise, const int64
 extern "C" int dsc_p_sample_f32(const float* x_t, const float* model_out, const float* noise, const int64_t* t,
                                 const float* ca, const float* cb, const float* coef1, const float* coef2,
                                 const float* sigma, float* out, float* x0_out, int32_t mean_type, int32_t clip,
-                                int32_t b, int64_t inner, dsc_stream_t stream) {
-    if (!x_t || !model_out || !noise || !t || !coef1 || !coef2 || !sigma || !out || b < 1 || inner < 1) return DSC_EINVAL;
+                                int32_t b, int64_t inner, int32_t num_timesteps, dsc_stream_t stream) {
+    if (!x_t || !model_out || !noise || !t || !coef1 || !coef2 || !sigma || !out || b < 1 || inner < 1 || num_timesteps < 1)
+        return DSC_EINVAL;
     if (mean_type < DSC_MEAN_EPS || mean_type > DSC_MEAN_V) return DSC_EINVAL;
     if (mean_type != DSC_MEAN_X0 && (!ca || !cb)) return DSC_EINVAL;
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(p_sample_kernel, dim3(grid_x(inner), b), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x_t, model_out, noise, t, ca, cb, coef1, coef2, sigma, out, x0_out, mean_type, clip, inner);
+                       x_t, model_out, noise, t, ca, cb, coef1, coef2, sigma, out, x0_out, mean_type, clip, inner, num_timesteps);
     DSC_LAUNCH_CHECK();
     return 0;
 }
@@ -161,12 +163,23 @@ extern "C" int dsc_postfilter_compact_f32(const float* samples, int32_t b, int32
 
 extern "C" int dsc_complete_overwrite_f32(float* x, const float* partial, const float* noise, const int64_t* t,
                                           const float* sqrt_ac, const float* sqrt_1mac, int32_t b, int32_t n,
-                                          int32_t p, int32_t c, dsc_stream_t stream) {
-    if (!x || !partial || !noise || !t || !sqrt_ac || !sqrt_1mac || b < 1 || n < 1 || p < 1 || p > n || c < 1)
+                                          int32_t p, int32_t c, int32_t num_timesteps, dsc_stream_t stream) {
+    if (!x || !partial || !noise || !t || !sqrt_ac || !sqrt_1mac || b < 1 || n < 1 || p < 1 || p > n || c < 1 || num_timesteps < 1)
         return DSC_EINVAL;
     DSC_CLEAR_STALE_ERROR();
     hipLaunchKernelGGL(complete_overwrite_kernel, dim3(grid_x((int64_t)p * c), b), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, partial, noise, t, sqrt_ac, sqrt_1mac, n, p, c);
+                       static_cast<hipStream_t>(stream), x, partial, noise, t, sqrt_ac, sqrt_1mac, n, p, c, num_timesteps);
     DSC_LAUNCH_CHECK();
     return 0;
+}
+
+unsigned dsc_bad_index_diffusion(bool reset) { return dsc_read_bad_index_count(reset); }
+
+// Number of out-of-range device indices (timesteps outside [0, num_timesteps)) that kernels had to clamp since the
+// last reset -- 0 in every correct run.  Synchronising (device-to-host reads of two counters): a test / debugging facility.
+extern "C" int64_t dsc_device_error_count(int32_t reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const unsigned a = dsc_bad_index_diffusion(reset != 0), b = dsc_bad_index_train(reset != 0);
+    if (a == 0xffffffffu || b == 0xffffffffu) return -1;
+    return (int64_t)a + b;
 }

@@ -53,14 +53,6 @@ __device__ __forceinline__ float dsc_act(float x, int act) {
 // x phi(x) takes its Gaussian density from the exponential the erf approximation computes anyway (exp(-(x/sqrt2)^2) = exp(-x^2/2)) --
 // one v_rcp, one v_exp, ~14 FMAs; SiLU' uses the hardware reciprocal.  (Round-4 first form: libm expf twice + a division, ~45 VALU
 // per element: the fused launches lost to the epilogue what the removed activation-backward launches had saved.)
-// Block size of the softmax-attention kernels (forward: blocks.hip, backward: train.hip): four lanes per token, one pass over the
-// tokens whenever they fit 512 threads (N = 80: 320 threads, five waves; N <= 64: 256 as before), host side only.
-static inline unsigned dsc_attention_threads(int n) {
-    if (n <= 64) return 256;
-    const int waves = (n + 15) / 16;
-    return waves >= 8 ? 512u : 64u * (unsigned)waves;
-}
-
 __device__ __forceinline__ float dsc_act_grad(float xv, int act) {
     if (act == DSC_ACT_GELU) {
         const float a = fabsf(xv) * 0.70710678118654752440f;
@@ -79,6 +71,14 @@ __device__ __forceinline__ float dsc_act_grad(float xv, int act) {
     }
     if (act == DSC_ACT_LEAKY01) return xv > 0.0f ? 1.0f : 0.1f;
     return 1.0f;
+}
+
+// Block size of the softmax-attention kernels (forward: blocks.hip, backward: train.hip): four lanes per token, one pass over the
+// tokens whenever they fit 512 threads (N = 80: 320 threads, five waves; N <= 64: 256 as before), host side only.
+static inline unsigned dsc_attention_threads(int n) {
+    if (n <= 64) return 256;
+    const int waves = (n + 15) / 16;
+    return waves >= 8 ? 512u : 64u * (unsigned)waves;
 }
 
 // butterfly reductions over the 64 lanes of a wave
@@ -117,5 +117,35 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s);
 
 // train.hip: deterministic slab reduction of a grouped weight-gradient launch (used by both arithmetics)
 int dsc_launch_reduce_grouped(const dsc_tn_group* groups_dev, int count, int total_tiles, int splits, const float* workspace, hipStream_t s);
+
+// Out-of-range device indices (a timestep outside the schedule tables, a gather row outside its table): every kernel that indexes a
+// table with a DEVICE value clamps it into range -- memory-safe whatever the caller left in the vector (after a finished hipGraph
+// reverse loop the in-graph timestep is -1) -- and the elementwise DDPM kernels also count the event in a per-translation-unit
+// counter that dsc_device_error_count() sums (tests read it; a correct run leaves it at 0).  Units that use it define
+// DSC_BAD_INDEX_COUNTER before including this header.
+#ifdef DSC_BAD_INDEX_COUNTER
+static __device__ unsigned int dsc_bad_index_count = 0;
+__device__ __forceinline__ int64_t dsc_checked_index(int64_t v, int64_t n) {
+    if (v < 0 || v >= n) {
+        atomicAdd(&dsc_bad_index_count, 1u);
+        return v < 0 ? 0 : n - 1;
+    }
+    return v;
+}
+static inline unsigned dsc_read_bad_index_count(bool reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(dsc_bad_index_count), sizeof(v)) != hipSuccess) return 0xffffffffu;
+    if (reset && v) {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(dsc_bad_index_count), &z, sizeof(z));
+    }
+    return v;
+}
+#endif
+// per-unit readers behind dsc_device_error_count (diffusion.hip)
+unsigned dsc_bad_index_diffusion(bool reset);
+unsigned dsc_bad_index_train(bool reset);
+// clamp only (GEMM prologues: no counter, no branch)
+__device__ __forceinline__ int64_t dsc_clamp_index(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
 static inline bool dsc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
                 const int f = tid + T * j;                     // (scene, half, column) flattened
                 const int sc = f / (2 * BN), hc = f % (2 * BN);
                 const int scc = sc < scenes_here ? sc : 0;     // slots past the block's scenes re-stage scene 0 (never read)
-                srow[j] = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + scc : p.ss_index[scene0 + scc];
+                srow[j] = (p.ss_mode == DSC_SS_PER_SCENE) ? scene0 + scc : dsc_clamp_index(p.ss_index[scene0 + scc], p.ss_rows);
                 soff[j] = (hc >= BN ? p.n : 0) + col0 + (hc % BN);
             }
             float sval[SSV];
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(const dsc_gemm_ar
                             // slots -- the host avoids them) the scene's row straight from the global table
                             const float* ss = ss_lds ? ssl + sc * (2 * BN) + (wn * TN + tn) * 32 + cq * 4
                                 : ssb + (p.ss_mode == DSC_SS_PER_SCENE ? scene0 + sc
-                                         : p.ss_mode == DSC_SS_BY_INDEX ? p.ss_index[scene0 + sc] : (int64_t)rowss[tl]) * p.ld_ss;
+                                         : p.ss_mode == DSC_SS_BY_INDEX ? dsc_clamp_index(p.ss_index[scene0 + sc], p.ss_rows) : (int64_t)rowss[tl]) * p.ld_ss;
                             const f32x4 sc4 = *reinterpret_cast<const f32x4*>(ss);
                             const f32x4 sh4 = *reinterpret_cast<const f32x4*>(ss + (ss_lds ? BN : p.n));
                             v01 = v01 * (f32x2{sc4[0], sc4[1]} + 1.0f) + f32x2{sh4[0], sh4[1]};

@@ -115,7 +115,7 @@ extern "C" int dsc_gemm_gn_silu_f32(const dsc_gemm_args* a, dsc_stream_t stream)
         if (!a->scale_shift) return DSC_EINVAL;
         if (!dsc_aligned16(a->scale_shift) || (a->ld_ss & 3)) return DSC_EALIGN;
         if (a->ss_mode < DSC_SS_NONE || a->ss_mode > DSC_SS_BY_INDEX) return DSC_EINVAL;
-        if (a->ss_mode == DSC_SS_BY_INDEX && !a->ss_index) return DSC_EINVAL;
+        if (a->ss_mode == DSC_SS_BY_INDEX && (!a->ss_index || a->ss_rows < 1)) return DSC_EINVAL;
     } else if (a->scale_shift) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = dsc_gemm_try_split(a, true, s);

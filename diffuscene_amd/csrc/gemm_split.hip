@@ -382,7 +382,7 @@ __device__ __forceinline__ void gemm_split_tile(const dsc_gemm_args& p, const in
         const bool per_row = p.ss_mode == DSC_SS_PER_TOKEN || p.ss_mode == DSC_SS_PER_SLOT;   // applied per element below
         f32x4 ga[4], be[4], sc[4], sh[4];
         int64_t ssrow = scene;
-        if (p.ss_mode == DSC_SS_BY_INDEX) ssrow = p.ss_index[scene];
+        if (p.ss_mode == DSC_SS_BY_INDEX) ssrow = dsc_clamp_index(p.ss_index[scene], p.ss_rows);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                    // issued first: their latency hides under the statistics
             ga[j] = *reinterpret_cast<const f32x4*>(p.gamma + cbase + j * 16);
@@ -573,6 +573,12 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
 extern "C" int dsc_gemm_arithmetic(const dsc_gemm_args* a, int32_t gn) {
     if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0) return DSC_EINVAL;
     return select_tile(a, gn != 0) >= 0 ? 1 : 0;
+}
+
+// The tile class (DSC_TILE_* of the header; the enum above) the split-bf16 path would run this launch on, or -1
+extern "C" int dsc_gemm_split_tile(const dsc_gemm_args* a, int32_t gn) {
+    if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0) return DSC_EINVAL;
+    return select_tile(a, gn != 0);
 }
 
 extern "C" int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream) {

@@ -9,6 +9,7 @@
 //   linear_attention_bwd_kernel / attention_bwd_kernel   one (scene, head) per block
 //   act_bwd_kernel, transpose_kernel
 // Input gradients (dA = dY . W) reuse the forward NT kernel (gemm_mfma.hip) on transposed weights.
+#define DSC_BAD_INDEX_COUNTER
 #include "dsc_common.h"
 
 namespace {
@@ -1715,6 +1716,7 @@ struct LossArgs {
     float* losses; float* parts; float* dout;
     int n, c, tr, sz, bb, nc, no, nf;
     int separate, iou, mean_type;
+    int T;                        // rows of the schedule tables: t[b] is held to [0, T)
     int arrange;                  // re-arrangement model: x = [translation | angle], losses = l_trans + l_angle (:558-571)
     float grad_scale;             // dout = grad_scale * d losses[b] / d out[b]   (1/B for loss = losses.mean())
     float c_lo[3], c_span[3], s_lo[3], s_span[3];
@@ -1736,7 +1738,7 @@ __global__ __launch_bounds__(256) void ddpm_loss_kernel(const LossArgs p) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = p.n, C = p.c;
     const long base = (long)b * N * C;
-    const int64_t tv = p.t[b];
+    const int64_t tv = dsc_checked_index(p.t[b], p.T);
     const float lw = p.loss_weight[tv];
     const int c_trans = p.tr, c_size = p.tr + p.sz, c_bbox = p.bb, c_class = p.bb + p.nc;
     const int c_obj0 = (p.no == 0) ? c_class - 1 : c_class, c_obj1 = c_class + p.no;
@@ -1906,8 +1908,8 @@ extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const fl
                                  float* losses, float* parts, float* dout, int32_t b, int32_t n, int32_t c,
                                  int32_t translation_dim, int32_t size_dim, int32_t bbox_dim, int32_t class_dim,
                                  int32_t objectness_dim, int32_t objfeat_dim, int32_t loss_separate, int32_t loss_iou,
-                                 int32_t mean_type, float grad_scale, dsc_stream_t stream) {
-    if (!target || !out || !x_t || !t || !loss_weight || !losses || !parts || !dout || b < 1 || n < 1) return DSC_EINVAL;
+                                 int32_t mean_type, float grad_scale, int32_t num_timesteps, dsc_stream_t stream) {
+    if (!target || !out || !x_t || !t || !loss_weight || !losses || !parts || !dout || b < 1 || n < 1 || num_timesteps < 1) return DSC_EINVAL;
     if (n > LOSS_MAXN) return DSC_ERANGE;
     if (c != bbox_dim + class_dim + objectness_dim + objfeat_dim) return DSC_EINVAL;
     // the re-arrangement model diffuses [translation | angle] only (diffusion_ddpm.py:558-571): no size / class /
@@ -1923,6 +1925,7 @@ extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const fl
     p.n = n; p.c = c; p.tr = translation_dim; p.sz = size_dim; p.bb = bbox_dim; p.nc = class_dim; p.no = objectness_dim;
     p.nf = objfeat_dim; p.separate = loss_separate; p.iou = loss_iou; p.mean_type = mean_type;
     p.arrange = arrange ? 1 : 0;
+    p.T = num_timesteps;
     p.grad_scale = grad_scale;
     if (bounds)
         for (int k = 0; k < 3; ++k) {
@@ -1934,6 +1937,8 @@ extern "C" int dsc_ddpm_loss_f32(const float* target, const float* out, const fl
     DSC_LAUNCH_CHECK();
     return 0;
 }
+
+unsigned dsc_bad_index_train(bool reset) { return dsc_read_bad_index_count(reset); }
 
 // ------------------------------------------------------------------------------------------------------
 // Strided 2-D helpers of the static training plan (train_plan.py): gradient accumulation of multi-consumer activations

@@ -23,6 +23,23 @@ DEC_PAD = 32        # rows per head of the stacked, zero-padded decoder output p
                     # (objfeat_dim = 64) raises the engine's dec_pad to the next multiple
 
 
+def _own(t):
+    """What a plan keeps for a raw pointer it baked into a launch: tensors as they are, an nn.Parameter as a detached ALIAS of its
+    current storage.  `p.data = ...` (flat.FlatStorage re-homes every parameter on the first training step; module.to()) swaps a
+    Parameter's storage in place and frees the old one; the alias keeps the storage the pointer refers to alive for as long as the
+    plan (and any hipGraph captured from it) lives, so a plan that outlives such a move reads stale weights -- and says so, see
+    Plan.run -- instead of freed memory."""
+    if isinstance(t, torch.nn.Parameter):
+        return t.detach()
+    if isinstance(t, (tuple, list)):
+        return tuple(_own(u) for u in t)
+    return t
+
+
+class StalePlanError(RuntimeError):
+    pass
+
+
 class _Pool:
     def __init__(self, device):
         self.device = device
@@ -49,6 +66,7 @@ class Plan:
 
     def __init__(self, eng, B, N, ctx_mode, ctx_dim, L, text_dim, time_table=False):
         self.eng, self.B, self.N, self.M = eng, B, N, B * N
+        self.generation = eng.generation          # the parameter storages this plan's pointers refer to (DenoiserEngine.refresh)
         dev = eng.device
         self.pool = _Pool(dev)
         self.keep = []          # tensors / structs referenced by raw pointer
@@ -88,7 +106,7 @@ class Plan:
         pl = self.eng.planes_of(w) if ops.gemm_would_use_split(g) else None       # planes only for launches that will use them
         if pl is not None:
             g.w_planes = pl.data_ptr()
-        self.keep.append((g, a, w, out, bias, a2, residual, pl))
+        self.keep.append(_own((g, a, w, out, bias, a2, residual, pl)))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
 
@@ -106,7 +124,7 @@ class Plan:
         pl = self.eng.planes_of(stacked) if (whole and ops.gemm_would_use_split(g)) else None
         if pl is not None:
             g.w_planes = pl.data_ptr()
-        self.keep.append((g, a, w, out, bias, pl))
+        self.keep.append(_own((g, a, w, out, bias, pl)))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
 
@@ -117,12 +135,12 @@ class Plan:
         pl = self.eng.planes_of(w) if ops.gemm_would_use_split(g, gn=True) else None
         if pl is not None:
             g.w_planes = pl.data_ptr()
-        self.keep.append((g, a, w, out, bias, a2, residual, gamma, beta, ss, pl))
+        self.keep.append(_own((g, a, w, out, bias, a2, residual, gamma, beta, ss, pl)))
         self.steps.append((_lib.fn("dsc_gemm_gn_silu_f32"), (C.byref(g),)))
         return out
 
     def call(self, name, *args, keep=()):
-        self.keep.append(keep)
+        self.keep.append(_own(keep))
         self.steps.append((_lib.fn(name), args))
 
     def hoist(self, first):
@@ -133,7 +151,17 @@ class Plan:
             return True
         return False
 
+    def check_current(self):
+        """Raise if the network's parameters moved to other storage since this plan was built (the engine noticed in refresh()): the
+        pointers baked into the launches then refer to the OLD storages -- kept alive by the plan, so nothing faults, but the values
+        are no longer the model's."""
+        if self.generation != self.eng.generation:
+            raise StalePlanError("diffuscene_amd: this launch plan was built for parameter storages the model no longer uses (flat storage "
+                                 "of the first training step, module.to(), load into new tensors): rebuild it -- DenoiserEngine.prepare() / "
+                                 "graph_sample_loop() do -- instead of running or replaying it")
+
     def run_pre(self):
+        self.check_current()
         s = ops.stream_ptr()
         for f, a in self.pre_steps:
             rc = f(*a, s)
@@ -156,7 +184,7 @@ class Plan:
         if (M + 95) // 96 >= 160:
             g = ops.make_gemm_args(a, conv.weight, out, conv.bias, None, residual, gamma=ln_gain.view(-1), beta=ln_gain.view(-1),
                                    eps=1e-5)
-            self.keep.append((g, a, conv.weight, out, conv.bias, residual, ln_gain))
+            self.keep.append(_own((g, a, conv.weight, out, conv.bias, residual, ln_gain)))
             self.steps.append((_lib.fn("dsc_gemm_layernorm_f32"), (C.byref(g),)))
             return out
         o = self.gemm(a, conv.weight, self.pool.get(M, D), conv.bias)
@@ -281,7 +309,8 @@ class Plan:
                 items[i].x, items[i].ldx, items[i].k_in = xs.data_ptr(), self.x_in.stride(0), k
                 items[i].w, items[i].ldw, items[i].bias = seq[0].weight.data_ptr(), k, seq[0].bias.data_ptr()
                 items[i].y, items[i].ldy = h1.data_ptr() + 4 * i * D, H * D
-            self.call("dsc_linear_smallk_grouped_f32", items, H, M, D, ACT_GELU, keep=(items, h1))
+            self.call("dsc_linear_smallk_grouped_f32", items, H, M, D, ACT_GELU,
+                      keep=(items, h1, [(seq[0].weight, seq[0].bias) for seq, _, _ in e.enc_heads]))
             h2 = pool.get(M, H * 2 * D)
             self.gemm_batched(h1[:, :D], e.enc_w2[:2 * D], h2[:, :2 * D], e.enc_b2[:2 * D], H, D, 2 * D * D, 2 * D, 2 * D,
                               act_out=ACT_GELU)
@@ -295,7 +324,7 @@ class Plan:
             k = net.channels
             self.call("dsc_linear_smallk_f32", self.x_in.data_ptr(), self.x_in.stride(0), k,
                       net.init_conv.weight.data_ptr(), k, net.init_conv.bias.data_ptr(), x.data_ptr(), D, M, D,
-                      ACT_NONE, keep=(x,))
+                      ACT_NONE, keep=(x, net.init_conv.weight, net.init_conv.bias))
         r = x           # `r = x.clone()` of the reference: the buffer is simply never recycled
         skips = []
         text = net.text_condition
@@ -381,6 +410,7 @@ class Plan:
             self.gemm(x, net.final_conv.weight, self.out, net.final_conv.bias)
 
     def run(self):
+        self.check_current()
         s = ops.stream_ptr()
         for f, a in self.steps:
             rc = f(*a, s)
@@ -398,6 +428,7 @@ class DenoiserEngine:
                                "fallback -- use the oracle in tests" % device)
         self.net, self.device = net, device
         self.plans = {}
+        self.generation = 0           # bumped whenever a parameter's storage moved (refresh): plans of an older generation are stale
         self.sig = None
         self.ws = {}
         # split-bf16 GEMM path (csrc/gemm_split.hip): bf16 planes of every weight a plan multiplies with, re-split by refresh()
@@ -480,6 +511,14 @@ class DenoiserEngine:
         from .optim import weights_epoch
         return hash((weights_epoch(),) + tuple((p._version, p.data_ptr()) for p in self.net.parameters()))
 
+    def params_moved(self):
+        """True (and every existing plan is marked stale) when a parameter lives in other storage than at the last refresh()."""
+        ptrs = tuple(p.data_ptr() for p in self.net.parameters())
+        if getattr(self, "_ptrs", None) is not None and self._ptrs != ptrs:
+            self.refresh()
+            return True
+        return False
+
     def refresh(self, force=False):
         """Re-derive standardised / packed weights if any parameter changed (in-place update or reallocation)."""
         sig = self._signature()
@@ -487,6 +526,8 @@ class DenoiserEngine:
             return
         ptrs = tuple(p.data_ptr() for p in self.net.parameters())
         if getattr(self, "_ptrs", None) != ptrs:
+            if getattr(self, "_ptrs", None) is not None:
+                self.generation += 1    # plans (and graphs captured from them) still held elsewhere now refuse to run
             self.plans.clear()          # plans hold raw parameter pointers
             self._planes.clear()
             self._ptrs = ptrs

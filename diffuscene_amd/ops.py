@@ -80,6 +80,7 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
             raise RuntimeError("actgrad_x shape %s != (%d, %d)" % (tuple(actgrad_x.shape), g.m, g.n))
     if ss_index is not None:
         g.ss_index = _dev(ss_index, "ss_index", torch.int64).data_ptr()
+        g.ss_rows = scale_shift.shape[0]              # the device clamps every gathered row into the table
     if w_planes is not None:
         # (3, n, K); a grouped launch (batch set by the caller afterwards) passes the planes of the stacked weights (3, batch n, K)
         if (w_planes.dtype != torch.int16 or w_planes.dim() != 3 or w_planes.shape[0] != 3 or w_planes.shape[1] % g.n
@@ -295,6 +296,17 @@ def _c(t, name):
     return t
 
 
+def _table_rows(*tables):
+    """Rows of the schedule tables a kernel indexes with the device timestep (it clamps t into them): all must agree."""
+    rows = {int(tb.numel()) for tb in tables if tb is not None}
+    if len(rows) != 1:
+        raise RuntimeError("diffuscene_amd: schedule tables of different lengths %s" % sorted(rows))
+    for tb in tables:
+        if tb is not None:
+            _c(tb, "schedule table")
+    return rows.pop()
+
+
 def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac, want_v=False):
     _c(x0, "x0"); _c(noise, "noise"); _dev(t, "t", torch.int64)
     xt = torch.empty_like(x0)
@@ -302,7 +314,7 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac, want_v=False):
     b = x0.shape[0]
     _lib.check(_lib.fn("dsc_q_sample_f32")(x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(),
                                            sqrt_1mac.data_ptr(), xt.data_ptr(), v.data_ptr() if want_v else None,
-                                           b, x0.numel() // b, stream_ptr()), "dsc_q_sample_f32")
+                                           b, x0.numel() // b, _table_rows(sqrt_ac, sqrt_1mac), stream_ptr()), "dsc_q_sample_f32")
     return (xt, v) if want_v else xt
 
 
@@ -316,7 +328,8 @@ def p_sample(x_t, model_out, noise, t, ca, cb, coef1, coef2, sigma, mean_type, c
                                            cb.data_ptr() if cb is not None else None,
                                            coef1.data_ptr(), coef2.data_ptr(), sigma.data_ptr(), out.data_ptr(),
                                            x0_out.data_ptr() if x0_out is not None else None,
-                                           mean_type, 1 if clip else 0, b, x_t.numel() // b, stream_ptr()),
+                                           mean_type, 1 if clip else 0, b, x_t.numel() // b,
+                                           _table_rows(ca, cb, coef1, coef2, sigma), stream_ptr()),
                "dsc_p_sample_f32")
     return out
 
@@ -345,7 +358,7 @@ def complete_overwrite(x, partial, noise, t, sqrt_ac, sqrt_1mac):
     p = partial.shape[1]
     _lib.check(_lib.fn("dsc_complete_overwrite_f32")(x.data_ptr(), partial.data_ptr(), noise.data_ptr(), t.data_ptr(),
                                                      sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(), b, n, p, c,
-                                                     stream_ptr()), "dsc_complete_overwrite_f32")
+                                                     _table_rows(sqrt_ac, sqrt_1mac), stream_ptr()), "dsc_complete_overwrite_f32")
     return x
 
 
@@ -513,5 +526,6 @@ def ddpm_loss(target, out, x_t, t, loss_weight, ca, cb, alphas_cumprod, bounds, 
         alphas_cumprod.data_ptr() if alphas_cumprod is not None else None, barr,
         losses.data_ptr(), parts.data_ptr(), dout.data_ptr(), B, N, Cc, dims["translation_dim"], dims["size_dim"],
         dims["bbox_dim"], dims["class_dim"], dims["objectness_dim"], dims["objfeat_dim"], 1 if separate else 0,
-        1 if iou else 0, mean_type, float(grad_scale), stream_ptr()), "dsc_ddpm_loss_f32")
+        1 if iou else 0, mean_type, float(grad_scale), _table_rows(loss_weight, ca, cb, alphas_cumprod), stream_ptr()),
+        "dsc_ddpm_loss_f32")
     return losses, parts, dout

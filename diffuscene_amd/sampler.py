@@ -134,7 +134,22 @@ class _StepGraph:
         with torch.cuda.graph(self.graph):
             step()
 
+    def check_current(self):
+        """The captured launches hold raw pointers into the parameter storages of capture time.  If the parameters have moved since
+        (the first training step re-homes them into flat storage, module.to() ...) the graph is stale: refuse to replay it.  (The
+        plans keep the old storages alive, so a stale replay could not fault -- it would silently sample from old weights.)"""
+        for p in self.plans:
+            p.eng.params_moved()
+            p.check_current()
+
+    def replay(self, n=1):
+        """n captured reverse steps on the current stream (x, t and the conditioning buffers are the graph's own state)."""
+        self.check_current()
+        for _ in range(n):
+            self.graph.replay()
+
     def run(self, x_T, total_steps, noise_buffer=None, partial=None, partial_noise=None):
+        self.check_current()
         self.x.copy_(x_T)
         self.t.fill_(total_steps - 1)
         if self.partial is not None:
@@ -147,7 +162,11 @@ class _StepGraph:
                 self.pdraw.fill_(0)
         for _ in range(total_steps):
             self.graph.replay()
-        return self.x.clone()
+        out = self.x.clone()
+        # the in-graph timestep now holds -1: park it on a valid row, so that one replay too many (a caller driving `graph` directly)
+        # still indexes the schedule tables in range (the kernels clamp and count it either way: dsc_device_error_count)
+        self.t.fill_(0)
+        return out
 
 
 def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cross, clip_denoised, total_steps,
@@ -164,6 +183,7 @@ def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cros
                None if condition_cross is None else tuple(condition_cross.shape))
         g = diff._graphs.get(key)
         eng = model.engine(device)
+        eng.params_moved()              # parameters re-homed since the capture (first training step, .to()): the engine drops its plans
         if g is None or g.plan is not eng.plans.get(_plan_key(g)):
             g = _StepGraph(diff, model, tuple(shape), device, condition, condition_cross, clip_denoised, replay, pshape)
             diff._graphs = {key: g}           # one live graph per diffusion object

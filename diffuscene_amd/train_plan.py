@@ -315,7 +315,7 @@ class HipBackend:
         b = x0.shape[0]
         return self._call("dsc_q_sample_f32", x0.data_ptr(), noise.data_ptr(), t.data_ptr(), sqrt_ac.data_ptr(),
                           sqrt_1mac.data_ptr(), xt.data_ptr(), v.data_ptr() if v is not None else None, b, x0.numel() // b,
-                          keep=(x0, noise, t, sqrt_ac, sqrt_1mac, xt, v))
+                          int(sqrt_ac.numel()), keep=(x0, noise, t, sqrt_ac, sqrt_1mac, xt, v))
 
     def loss(self, target, out, x_t, t, tb, ca, cb, bounds, dims, separate, iou, mean_type, losses, parts, dout, scale):
         B, N, Cc = out.shape
@@ -325,7 +325,7 @@ class HipBackend:
                           cb.data_ptr() if cb is not None else None, tb["alphas_cumprod"].data_ptr(), barr,
                           losses.data_ptr(), parts.data_ptr(), dout.data_ptr(), B, N, Cc, dims["translation_dim"],
                           dims["size_dim"], dims["bbox_dim"], dims["class_dim"], dims["objectness_dim"], dims["objfeat_dim"],
-                          1 if separate else 0, 1 if iou else 0, mean_type, float(scale),
+                          1 if separate else 0, 1 if iou else 0, mean_type, float(scale), int(tb["loss_weight"].numel()),
                           keep=(target, out, x_t, t, tb, ca, cb, barr, losses, parts, dout))
 
     # -- backward ops

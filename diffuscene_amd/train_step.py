@@ -22,6 +22,19 @@ _PART_KEYS = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class'
               'loss.liou', 'loss.bbox_iou')
 
 
+DDP_FLUSH_SCHEDULES = ("single", "block", "thirds")
+
+
+def ddp_flush_schedule():
+    """The data-parallel flush schedule named by DSC_DDP_FLUSH (PlanRunner.plan_for documents the three); 'end' = 'single'."""
+    flush = os.environ.get("DSC_DDP_FLUSH", "single")
+    if flush == "end":
+        flush = "single"
+    if flush not in DDP_FLUSH_SCHEDULES:
+        raise ValueError("DSC_DDP_FLUSH=%r: must be 'single' (default; alias 'end'), 'block' or 'thirds'" % flush)
+    return flush
+
+
 def plan_supported(model):
     """The static plan covers every shipped training configuration; anything else keeps the autograd path (same kernels)."""
     if os.environ.get("DSC_TRAIN_PLAN", "1") == "0":
@@ -87,15 +100,16 @@ class PlanRunner:
         # data parallel, DSC_DDP_FLUSH = when the grouped weight-gradient launches run (the single-GPU plan keeps ONE at the end of the
         # backward); measured on one GPU with a world-1 RCCL group (bench.py --ddp-selftest, profiles/r04_bench_ddp_selftest.json; B = 256 /
         # B = 32 scenes per GPU, over the single-GPU graph step):
-        #   "block" (default)  a flush every few ResnetBlocks, 7 graph segments: buckets leave all through the backward   +5.2 % / +10.8 %
-        #   "end"              whenever a third of G is pending: 3 launches, two thirds of the exchange can overlap       +9.2 % /  +8.7 %
-        #   "single"           the single-GPU schedule unchanged: cheapest compute, NO overlap (every bucket finishes with
-        #                      the last launch); the right choice when the 311 MB all-reduce is faster than ~1 ms          +1.5 % /  +1.8 %
-        flush = os.environ.get("DSC_DDP_FLUSH", "block")
-        if flush not in ("end", "block", "single"):
-            raise ValueError("DSC_DDP_FLUSH=%r: must be 'block' (default), 'end' or 'single'" % flush)
+        #   "single" (default) the single-GPU schedule unchanged: cheapest compute, NO overlap (every bucket finishes with the
+        #                      last launch, the whole exchange is exposed)                                              +1.5 % /  +1.8 %
+        #   "block"            a flush every few ResnetBlocks, 7 graph segments: buckets leave all through the backward   +5.2 % / +10.8 %
+        #   "thirds"           whenever a third of G is pending: 3 launches, two thirds of the exchange can overlap       +9.2 % /  +8.7 %
+        #   "end"              alias of "single" (what the name meant up to round 3: the single-GPU schedule, flushed at the end)
+        # The default is the cheapest schedule MEASURED: no multi-GPU run exists yet that shows the overlap of "block" paying
+        # for its extra launches; `bench.py --gpus N` times all three on the node and uses the fastest.
+        flush = ddp_flush_schedule()
         per_block = distributed and flush == "block"
-        thirds = distributed and flush == "end"
+        thirds = distributed and flush == "thirds"
         from ._lib import split_enabled
         arith = split_enabled() if PlanRunner.backend_factory is None else None      # plans bake the arithmetic in (planes, TN form)
         key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block, thirds, arith)

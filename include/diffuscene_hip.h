@@ -93,6 +93,9 @@ typedef struct dsc_gemm_args {
      *                                         of the NEXT layer applies the derivative of the activation whose saved pre-activation
      *                                         is actgrad_x (act_out names the activation; it is not applied to y) */
     const float* actgrad_x; int64_t ld_actgrad;
+    /* DSC_SS_BY_INDEX: rows of the scale_shift table (>= 1).  Every gathered index is clamped into [0, ss_rows) on the device, so a
+     * timestep vector left out of range (e.g. -1 after the last step of a captured reverse loop) cannot read outside the table. */
+    int32_t ss_rows;
 } dsc_gemm_args;
 
 int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
@@ -103,6 +106,21 @@ int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
 /* Which arithmetic dsc_gemm_f32 (gn = 0) / dsc_gemm_gn_silu_f32 (gn != 0) would use for this launch: 1 = the split-bf16 kernel (planes
  * supplied, shape / alignment covered, launch large enough to fill the chip, DSC_GEMM != f32), 0 = the exact-f32 MFMA kernel. */
 int dsc_gemm_arithmetic(const dsc_gemm_args* args, int32_t gn);
+
+/* Which TILE of the split-bf16 kernel the launch would run on (-1: none, the exact-f32 MFMA kernel takes it).  Tests use it to say
+ * which tile class a golden comparison exercised: the headline batch (B = 256, N = 80) runs the eight-wave GroupNorm tile, half of
+ * it the four-wave one -- same K order and product order per output element, bit-identical results (tests/test_gpu_split.py). */
+#define DSC_TILE_GN_32       0   /* 4 scenes of <= 32 tokens x 128 channels, 8 waves */
+#define DSC_TILE_GN_80_W8    1   /* 2 scenes of 65..80 tokens x 256 channels, 8 waves */
+#define DSC_TILE_GN_80_W4    2   /* 2 scenes of 65..80 tokens x 128 channels, 4 waves */
+#define DSC_TILE_GN_48       3
+#define DSC_TILE_GN_64       4
+#define DSC_TILE_160x256     5   /* dense rows, 8 waves */
+#define DSC_TILE_256x128     6
+#define DSC_TILE_128x128     7
+#define DSC_TILE_160x128_W4  8   /* dense rows, 4 waves */
+#define DSC_TILE_64x256      9
+int dsc_gemm_split_tile(const dsc_gemm_args* args, int32_t gn);
 
 /* The arithmetic switch of dsc_gemm_f32 / dsc_gemm_gn_silu_f32 / the grouped weight-gradient launch chosen by the host code -- the ONE
  * source of truth (the Python engine, the training plan and bench.py ask this function, nothing else parses the environment):
@@ -191,13 +209,20 @@ int dsc_activation_f32(const float* x, float* y, int64_t count, int32_t act, dsc
  * re-uploads them on every call, :220,:232,:284); t is int64 on the device; `inner` = N*C.
  * These kernels are compiled with -ffp-contract=off and reproduce the reference's fp32
  * expression order bit for bit.
+ * num_timesteps = rows of the coefficient tables: every kernel clamps the DEVICE value t[b] into [0, num_timesteps) before it
+ * indexes a table (reference: the tables are indexed by torch.gather, which raises on such a t; here the launch is asynchronous,
+ * so the access is made safe and the event is counted -- dsc_device_error_count).
  * ------------------------------------------------------------------------------------------- */
+
+/* Out-of-range device timesteps the kernels below (and dsc_ddpm_loss_f32) had to clamp since the last reset; 0 in a correct run.
+ * Synchronises the device (a test / debugging facility); -1 on a HIP error.  reset != 0 clears the counters. */
+int64_t dsc_device_error_count(int32_t reset);
 
 /* q_sample (:276-286) and, if v_out != NULL, _predict_v (:230-234) in one pass:
  *   x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise ;  v = sqrt_ac[t] * noise - sqrt_1mac[t] * x0 */
 int dsc_q_sample_f32(const float* x0, const float* noise, const int64_t* t,
                      const float* sqrt_ac, const float* sqrt_1mac,
-                     float* x_t, float* v_out, int32_t b, int64_t inner, dsc_stream_t stream);
+                     float* x_t, float* v_out, int32_t b, int64_t inner, int32_t num_timesteps, dsc_stream_t stream);
 
 /* p_mean_variance + p_sample for model_var_type 'fixedsmall' (:242-264, :305-352):
  *   x0 = (mean_type v)   ca[t]*x_t - cb[t]*model_out      ca=sqrt_ac,        cb=sqrt_1mac
@@ -211,7 +236,8 @@ int dsc_q_sample_f32(const float* x0, const float* noise, const int64_t* t,
 int dsc_p_sample_f32(const float* x_t, const float* model_out, const float* noise, const int64_t* t,
                      const float* ca, const float* cb, const float* coef1, const float* coef2,
                      const float* sigma, float* out, float* x0_out /* may be NULL */,
-                     int32_t mean_type, int32_t clip, int32_t b, int64_t inner, dsc_stream_t stream);
+                     int32_t mean_type, int32_t clip, int32_t b, int64_t inner, int32_t num_timesteps,
+                     dsc_stream_t stream);
 
 /* In-graph timestep bookkeeping for the captured reverse loop (:365-366): t[i] += delta. */
 int dsc_add_scalar_i64(int64_t* t, int32_t count, int64_t delta, dsc_stream_t stream);
@@ -227,7 +253,7 @@ int dsc_postfilter_compact_f32(const float* samples, int32_t b, int32_t n, int32
  * (b, n, c) are replaced by q_sample(partial, t, noise) (partial/noise are (b, p, c)). */
 int dsc_complete_overwrite_f32(float* x, const float* partial, const float* noise, const int64_t* t,
                                const float* sqrt_ac, const float* sqrt_1mac,
-                               int32_t b, int32_t n, int32_t p, int32_t c, dsc_stream_t stream);
+                               int32_t b, int32_t n, int32_t p, int32_t c, int32_t num_timesteps, dsc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training: hand-written backward of the denoiser (the reference relies on torch autograd through
@@ -326,7 +352,7 @@ int dsc_ddpm_loss_f32(const float* target, const float* out, const float* x_t, c
                       const float* bounds, float* losses, float* parts, float* dout, int32_t b, int32_t n, int32_t c,
                       int32_t translation_dim, int32_t size_dim, int32_t bbox_dim, int32_t class_dim,
                       int32_t objectness_dim, int32_t objfeat_dim, int32_t loss_separate, int32_t loss_iou,
-                      int32_t mean_type, float grad_scale, dsc_stream_t stream);
+                      int32_t mean_type, float grad_scale, int32_t num_timesteps, dsc_stream_t stream);
 
 /* Strided 2-D copy / accumulate (static training plan: staging of un-aligned column slices, gradient accumulation of
  * multi-consumer activations such as skip connections):  dst[r][c] = src[r][c]   /   dst[r][c] += src[r][c]. */

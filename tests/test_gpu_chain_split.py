@@ -121,3 +121,68 @@ def test_hundred_step_completion_at_b128(golden_dir, tmp_path, gemm_arith):
         _check_sums(res[-1], g, "complete.T%d" % COMPLETE_T)
     assert torch.equal(res[0], res[1])
     assert torch.equal(res[1][:, :COMPLETE_P], partial)
+
+
+def test_two_hundred_step_chain_at_b256(golden_dir, tmp_path):
+    """The HEADLINE batch: B = 256, N = 80 -- every GroupNorm launch on the EIGHT-wave tile <true,2,4,5> the benchmark's dominant kernel
+    is (asserted through dsc_gemm_split_tile on the plan's own argument structs) -- against the real reference's own p_sample_loop
+    (tests/golden/chain_b256.npz, oracle/make_golden_chain_b256.py: T = 200, replayed noise), eagerly and from the hipGraph, under
+    BOTH arithmetics in one test.  And the distance BETWEEN the two arithmetics on the final scenes: the chain's sensitivity to
+    rounding amplifies any difference, whichever kernel made it (the element-wise distance from the CPU reference is the chain's,
+    not the kernel's: it is the same for split and exact f32); |split - f32| pins the split arithmetic itself -- two GPU runs that
+    differ in nothing but the six-product split."""
+    from diffuscene_amd import _lib
+    from diffuscene_amd.sampler import NoiseReplay
+    from oracle import make_golden_chain_b256 as G
+    g = np.load(os.path.join(golden_dir, "chain_b256.npz"))
+    kw, x, cond = G.chain_inputs()
+    C, Bq, Nq, T = kw["channels"], G.B, G.N, G.T
+    noise = torch.empty((T + 1, Bq, Nq, C), dtype=torch.float32, device=dev())
+    for i in range(T + 1):
+        noise[i].copy_(G.chain_noise(i, (Bq, Nq, C)))
+    cond_d = cond[0].to(dev())[None].expand(Bq, -1, -1)
+    results = {}
+    prev = "split" if _lib.split_enabled() else "f32"
+    try:
+        for arith in ("split", "f32"):
+            _lib.set_gemm_arithmetic(arith)
+            net, diff = _model(tmp_path, T)
+            eng = net.engine(dev())
+            plan = eng.prepare(Bq, Nq, cond_d, None)
+            tiles = [_lib.fn("dsc_gemm_split_tile")(a, 1) for kind, a in plan.gemm_args() if kind == "gn"]
+            assert len(tiles) == 56
+            if arith == "split":
+                assert all(t == _lib.TILE_GN_80_W8 for t in tiles), "B=256, N=80: every GroupNorm launch must run the 8-wave tile: %s" % tiles
+            else:
+                assert all(t == -1 for t in tiles)
+            seen = {}
+            inner = diff._denoise
+
+            def watching(data, t, condition, condition_cross, seen=seen, inner=inner):
+                ti = int(t[0])
+                if ti in G.WATCH_T:
+                    seen[ti] = data.detach().clone()
+                return inner(data, t, condition, condition_cross)
+            with torch.no_grad():
+                yg = diff.gen_samples((Bq, Nq, C), dev(), condition=cond_d, noise_fn=NoiseReplay(noise), clip_denoised=True, graph=True)
+                diff._denoise = watching
+                y = diff.gen_samples((Bq, Nq, C), dev(), condition=cond_d, noise_fn=NoiseReplay(noise), clip_denoised=True, graph=False)
+                diff._denoise = inner
+            assert torch.equal(y, yg), "graph replay must reproduce the eager loop bit for bit (%s)" % arith
+            for ti in G.WATCH_T:
+                check(seen[ti][::32], g["loop.t%d.scenes32" % ti], "B=256 x_t at t=%d (%s)" % (ti, arith))
+                _check_sums(seen[ti], g, "loop.t%d" % ti)
+            check(y[::32], g["loop.T%d.scenes32" % T], "B=256 T=%d chain, every 32nd scene (%s)" % (T, arith))
+            _check_sums(y, g, "loop.T%d" % T)
+            results[arith] = y
+            del net, diff, eng, plan
+    finally:
+        _lib.set_gemm_arithmetic(prev)
+    a, b = results["split"].double(), results["f32"].double()
+    rel = float((a - b).norm() / b.norm())
+    worst = float((a - b).abs().max())
+    log = os.environ.get("DSC_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("B=256 T=%d chain, |split - f32|: %.3e norm-relative, %.3e max abs\n" % (T, rel, worst))
+    assert rel < 2e-5, "the two arithmetics drifted apart over the chain: %.3e norm-relative (max abs %.3e)" % (rel, worst)

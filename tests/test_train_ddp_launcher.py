@@ -80,15 +80,15 @@ def test_bench_self_spawns_one_rank_per_gpu():
     recs = sorted(_json_objects(r.stdout), key=lambda d: d["rank"])
     assert [d["rank"] for d in recs] == [0, 1] and all(d["world"] == 2 and d["gpus"] == 2 for d in recs)
     assert [d["local_rank"] for d in recs] == [0, 1] and all(d["master"] == "127.0.0.1" and d["scaling"] == "strong" for d in recs)
-    assert all(d["batch_per_rank"] == 128 and d["ddp_flush"] == "block" and d["ipc_legacy"] == "0" for d in recs)
+    assert all(d["batch_per_rank"] == 128 and d["ddp_flush"] == "single" and d["ipc_legacy"] == "0" for d in recs)
     # the driver's 8-GPU line, cold: `python bench.py --gpus 8` (strong scaling, another flush schedule through the environment) --
     # eight ranks rendezvous on 127.0.0.1, every rank sees its own local rank, the 32-scene shard and the flush mode
     r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", "strong"],
-                        env=dict(env, DSC_DDP_FLUSH="end"), capture_output=True, text=True, timeout=600)
+                        env=dict(env, DSC_DDP_FLUSH="thirds"), capture_output=True, text=True, timeout=600)
     assert r8.returncode == 0, r8.stdout + r8.stderr
     recs8 = sorted(_json_objects(r8.stdout), key=lambda d: d["rank"])
     assert [d["local_rank"] for d in recs8] == list(range(8)) and all(d["world"] == 8 and d["gpus"] == 8 for d in recs8)
-    assert all(d["batch_per_rank"] == 32 and d["ddp_flush"] == "end" and d["scaling"] == "strong" for d in recs8)
+    assert all(d["batch_per_rank"] == 32 and d["ddp_flush"] == "thirds" and d["scaling"] == "strong" for d in recs8)
     # under torchrun with a mismatching --gpus the script refuses instead of running a wrong configuration
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True,
