@@ -177,7 +177,7 @@ class SampleRunner:
         self.reset()
 
     def run(self, n):
-        self.g.replay(n)              # refuses a graph whose parameter pointers are stale (sampler._StepGraph.check_current)
+        self.g.replay_steps(n)              # refuses a graph whose parameter pointers are stale (sampler._StepGraph.check_current)
 
     def sync_weights(self):
         """After optimizer steps (weights updated in place): re-derive the standardised / packed / split weights and the per-timestep

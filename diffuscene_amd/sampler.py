@@ -142,7 +142,7 @@ class _StepGraph:
             p.eng.params_moved()
             p.check_current()
 
-    def replay(self, n=1):
+    def replay_steps(self, n=1):
         """n captured reverse steps on the current stream (x, t and the conditioning buffers are the graph's own state)."""
         self.check_current()
         for _ in range(n):

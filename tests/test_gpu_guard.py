@@ -115,17 +115,21 @@ def test_sampling_graph_that_outlives_the_parameter_move_refuses_to_replay(tmp_p
         first = dp.gen_samples(shape, dev, cond, cross, noise_fn=NoiseReplay(buf), graph=True)
     net = dp.model
     before = [p.data_ptr() for p in net.parameters()]
-    g.replay(1)                                              # current: runs
+    g.replay_steps(1)                                              # current: runs
     _, batch = bench.synth_batch(spec, dev, seed=100)
     opt = optimizer_factory({"optimizer": "Adam", "lr": 0.0}, filter(lambda p: p.requires_grad, model.parameters()))
     train_on_batch(model, opt, batch, {"training": {"max_grad_norm": 10}})     # lr 0: the weights keep their values, only their storage moves
-    assert sum(a != p.data_ptr() for a, p in zip(before, net.parameters())) > 400, "the training step did not re-home the parameters"
+    assert sum(a != p.data_ptr() for a, p in zip(before, net.parameters())) > 300, "the training step did not re-home the parameters"
     # every pointer the stale plan holds still refers to memory the plan itself keeps alive
     kept = []
-    for k in g.plan.keep:
-        for t in (k if isinstance(k, tuple) else (k,)):
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                kept.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
+
+    def walk(k):
+        if isinstance(k, (tuple, list)):
+            for u in k:
+                walk(u)
+        elif isinstance(k, torch.Tensor) and k.is_cuda:
+            kept.append((k.data_ptr(), k.data_ptr() + k.numel() * k.element_size()))
+    walk(g.plan.keep)
     olds = set(before)
     checked = 0
     for _, a in g.plan.gemm_args():
@@ -136,7 +140,7 @@ def test_sampling_graph_that_outlives_the_parameter_move_refuses_to_replay(tmp_p
                 checked += 1
     assert checked > 100
     with pytest.raises(engine.StalePlanError):
-        g.replay(1)
+        g.replay_steps(1)
     with pytest.raises(engine.StalePlanError):
         g.plan.run()
     with torch.no_grad():                                    # the public entry point notices, rebuilds, and (lr = 0) reproduces the result
@@ -180,3 +184,18 @@ def test_out_of_range_device_timestep_is_clamped_and_counted():
     y_bad = ops.gemm_gn_silu(a, w, bias, gamma, beta, ntok, scale_shift=ss, ss_mode=_lib.SS_BY_INDEX, ss_index=idx_bad)
     y_ok = ops.gemm_gn_silu(a, w, bias, gamma, beta, ntok, scale_shift=ss, ss_mode=_lib.SS_BY_INDEX, ss_index=idx_ok)
     assert torch.equal(y_bad, y_ok)
+    # the same on the split-bf16 kernel (a launch large enough for it: 256 scenes of 80)
+    if _lib.split_enabled():
+        Bq = 256
+        a = torch.randn(Bq * ntok, K, device=dev)
+        (pl,) = ops.split_planes([(w, None, False)])
+        idx_bad = torch.randint(0, rows, (Bq,), generator=torch.Generator().manual_seed(1)).to(dev)
+        idx_ok = idx_bad.clone()
+        idx_bad[0], idx_bad[100], idx_bad[255] = -1, rows, 2 ** 40
+        idx_ok[0], idx_ok[100], idx_ok[255] = 0, rows - 1, rows - 1
+        g = ops.make_gemm_args(a, w, torch.empty(Bq * ntok, n, device=dev), bias, gamma=gamma, beta=beta, tokens_per_scene=ntok,
+                               scale_shift=ss, ss_mode=_lib.SS_BY_INDEX, ss_index=idx_bad, w_planes=pl)
+        assert ops.gemm_uses_split(g, gn=True)
+        y_bad = ops.gemm_gn_silu(a, w, bias, gamma, beta, ntok, scale_shift=ss, ss_mode=_lib.SS_BY_INDEX, ss_index=idx_bad, w_planes=pl)
+        y_ok = ops.gemm_gn_silu(a, w, bias, gamma, beta, ntok, scale_shift=ss, ss_mode=_lib.SS_BY_INDEX, ss_index=idx_ok, w_planes=pl)
+        assert torch.equal(y_bad, y_ok)

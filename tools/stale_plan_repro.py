@@ -88,7 +88,7 @@ def run(config, round4, early_flat=None):
                 v = getattr(a, f)
                 if v and v in before:
                     ptrs.add(v)
-        g.replay(2)
+        g.replay_steps(2)
         torch.cuda.synchronize()
         _, batch = bench.synth_batch(spec, dev, seed=100)
         opt = optimizer_factory({"optimizer": "Adam", "lr": 2e-4}, filter(lambda p: p.requires_grad, model.parameters()))
@@ -98,10 +98,13 @@ def run(config, round4, early_flat=None):
         moved = sum(1 for p in net.parameters() if p.data_ptr() not in before)
         owners = []
         if not round4:
-            for keep in g.plan.keep:
-                for t in (keep if isinstance(keep, tuple) else (keep,)):
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        owners.append((t.data_ptr(), t.data_ptr() + max(t.numel() * t.element_size(), 1)))
+            def walk(k):
+                if isinstance(k, (tuple, list)):
+                    for u in k:
+                        walk(u)
+                elif isinstance(k, torch.Tensor) and k.is_cuda:
+                    owners.append((k.data_ptr(), k.data_ptr() + max(k.numel() * k.element_size(), 1)))
+            walk(g.plan.keep)
         res = {"config": config, "plan_keeps": "Parameter objects (round 4)" if round4 else "aliases of the storages (round 5)",
                "flat_storage_created": "before the sampling graph (round 5 bench.py)" if early_flat else "by the first training step, after the capture (round 4 bench.py)",
                "parameter_pointers_in_the_sampling_plan": len(ptrs),
@@ -110,7 +113,7 @@ def run(config, round4, early_flat=None):
             res["replay_of_the_stale_graph"] = "not attempted (round 4 had no check: it replayed, reading whatever the pointers reach)"
         else:
             try:
-                g.replay(1)
+                g.replay_steps(1)
                 torch.cuda.synchronize()
                 res["replay_of_the_stale_graph"] = "ran: no parameter moved (flat storage exists before the capture)"
             except engine.StalePlanError:
