@@ -38,10 +38,11 @@ def _as2d(w):
 
 class H:
     """Activation handle: forward tensor + (build-time) gradient tensor."""
-    __slots__ = ("t", "g", "ng", "act_of", "g_pre")
+    __slots__ = ("t", "g", "ng", "act_of", "g_pre", "uses")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.g, self.ng = t, None, needs_grad
+        self.uses = 0             # consumers counted while the forward list is built (TrainPlan._use)
         self.act_of = None        # (pre-activation tensor, kind) when this handle is act(pre-activation) with ONE consumer
         self.g_pre = None         # gradient w.r.t. the pre-activation, written directly by the consumer's input-gradient GEMM
 
@@ -202,13 +203,15 @@ class HipBackend:
         return holder
 
     # -- forward ops
-    def fuse_act_ok(self, a, w, out, a2=None):
+    def fuse_act_ok(self, a, w, out, a2=None, bias=None, preact=None, actgrad_x=None):
         """Can this product carry an activation epilogue of the training step (pre-activation also stored / result multiplied by the
-        derivative)?  Only the split-bf16 kernel implements them: ask the library whether it takes the launch."""
+        derivative)?  Only the split-bf16 kernel implements them: ask the library whether it takes the launch -- with the argument
+        struct of the launch itself (bias / preact / actgrad_x pointers and strides take part in its decision: alignment)."""
         from . import ops
         if not self.split or a.shape[0] < 256 or os.environ.get("DSC_FUSE_ACT", "1") == "0":      # (A/B switch of the measurement tools)
             return False
-        g = ops.make_gemm_args(a, w, out, None, a2)
+        g = ops.make_gemm_args(a, w, out, bias, a2, act_out=ACT_GELU if (preact is not None or actgrad_x is not None) else ACT_NONE,
+                               preact=preact, actgrad_x=actgrad_x)
         return ops.gemm_would_use_split(g) and self.planes_of(w, a.shape[0]) is not None
 
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE, preact=None, actgrad_x=None):
@@ -708,6 +711,13 @@ class TrainPlan:
         produce(dst, old)
         h.g = dst
 
+    @staticmethod
+    def _use(*handles):
+        """Count a forward consumer of each handle (the activation-derivative fusion of g_gemm needs "exactly one")."""
+        for h in handles:
+            if h is not None:
+                h.uses += 1
+
     def g_gemm(self, a, a2, dy, wt):
         """grad([a | a2]) += dy @ wt^T-layout weight (wt is [K, n]: the GEMM computes dy . wt^T)."""
         k1 = a.t.shape[1]
@@ -715,10 +725,11 @@ class TrainPlan:
         if a2 is None:
             if not a.ng:
                 return
-            if (a.act_of is not None and a.g is None and a.g_pre is None and dy.shape[1] <= 4096
-                    and hasattr(self.be, "fuse_act_ok") and self.be.fuse_act_ok(dy, wt, a.t)):
-                # a = act(u), this GEMM is its only consumer: d u = (dy . W) * act'(u) in the GEMM's epilogue -- the activation's
-                # backward launch (read u, read d a, write d u) disappears
+            if (a.act_of is not None and a.uses == 1 and a.g is None and a.g_pre is None and dy.shape[1] <= 4096
+                    and hasattr(self.be, "fuse_act_ok") and self.be.fuse_act_ok(dy, wt, a.t, actgrad_x=a.act_of[0])):
+                # a = act(u) and this GEMM is its ONLY consumer (counted while the forward was built, not inferred from the order of the
+                # backward): d u = (dy . W) * act'(u) in the GEMM's epilogue -- the activation's backward launch (read u, read d a,
+                # write d u) disappears.  An activation with a second consumer keeps the separate launch.
                 u, kind = a.act_of
                 a.g_pre = self.new(*a.t.shape)
                 self.emit(self.be.gemm(dy, wt, a.g_pre, act_out=kind, actgrad_x=u))
@@ -825,9 +836,11 @@ class TrainPlan:
         n, K = w2.shape
         rows = a.t.shape[0]
         y = H(out if out is not None else self.new(rows, n))
+        self._use(a, a2, residual)
         assert act_out == ACT_NONE, "training keeps the pre-activation (its backward needs it): use act="
+        # probed with the launch's own operands (bias, the pre-activation buffer): what the library refuses here it would refuse below
         fused = (act is not None and residual is None and out is None and hasattr(self.be, "fuse_act_ok")
-                 and self.be.fuse_act_ok(a.t, w2, y.t, a2.t if a2 is not None else None))
+                 and self.be.fuse_act_ok(a.t, w2, y.t, a2.t if a2 is not None else None, bias=bias, preact=y.t))
         if fused:
             ya_t = self.new(rows, n)
             self.emit(self.be.gemm(a.t, w2, ya_t, bias, a2.t if a2 is not None else None, None, act, preact=y.t))
@@ -899,9 +912,11 @@ class TrainPlan:
         def bw():
             if y.g_pre is not None:
                 # the consumer's input-gradient GEMM already applied act'(x) (g_gemm): its output IS d x
-                assert y.g is None, "an activation output whose derivative was fused must have exactly one consumer"
                 self.g_alias(x, y.g_pre)
-                return
+                if y.g is None:
+                    return
+                # (not reachable while g_gemm fuses single-consumer activations only; kept correct rather than asserted: a gradient that
+                # arrived un-fused gets act' applied by the separate launch and is added)
             if y.g is None or not x.ng:
                 return
             dy = y.g
@@ -919,6 +934,7 @@ class TrainPlan:
         w_std = self.ws_std[id(conv)]
         rows = a.t.shape[0]
         y, z = H(self.new(rows, D)), self.new(rows, D)
+        self._use(a, a2, residual)
         self.emit(self.be.gemm_gn(a.t, w_std, y.t, conv.bias, norm.weight, norm.bias, self.N, a2.t if a2 is not None else None,
                                   ss, ss_mode, residual.t if residual is not None else None, z))
 
@@ -970,6 +986,7 @@ class TrainPlan:
     def layernorm(self, x, gain, residual=None):
         g = gain.view(-1)
         y = H(self.new(*x.t.shape))
+        self._use(x, residual)
         self.emit(self.be.layernorm(x.t, g, y.t, residual.t if residual is not None else None))
 
         def bw():

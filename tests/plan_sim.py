@@ -93,7 +93,7 @@ class SimBackend:
                 s()
 
     # ---------------------------------------------------------------- forward
-    def fuse_act_ok(self, a, w, out, a2=None):
+    def fuse_act_ok(self, a, w, out, a2=None, bias=None, preact=None, actgrad_x=None):
         """The product backend fuses activation epilogues only into launches its split kernel takes; the dataflow of BOTH forms is
         exercised here: fused for products with >= `fuse_rows` activation rows, separate launches below."""
         return a.shape[0] >= getattr(self, "fuse_rows", 0)

@@ -244,6 +244,32 @@ def test_build_network_accepts_every_reference_yaml(golden_dir, tmp_path):
             assert "fc_text_f.weight" in keys and net.diffusion.model.text_condition
 
 
+def test_unet1d_constructor_refusals():
+    """what Unet1D accepts of the reference's keyword list (denoise_net.py:336-416) and what it refuses --
+    loudly, at construction, never by approximating."""
+    import contextlib
+    import io
+    from diffuscene_amd.networks.denoise_net import Unet1D
+    ok = dict(dim=512, dim_mults=(1, 1, 1, 1), channels=62, seperate_all=True, objectness_dim=0, class_dim=22, angle_dim=2, objfeat_dim=32,
+              context_dim=0, instanclass_dim=128)
+    with contextlib.redirect_stdout(io.StringIO()):
+        Unet1D(**dict(ok, dim_mults=(1, 1)))                                    # any number of levels
+        Unet1D(**dict(ok, init_dim=512, out_dim=62))
+        Unet1D(**dict(ok, seperate_all=False, channels=5, class_dim=0, objfeat_dim=0, angle_dim=2, size_dim=0))
+        Unet1D(**dict(ok, text_condition=True, text_dim=256))
+        Unet1D(**dict(ok, instanclass_dim=0))                                   # un-conditioned
+        refused = [dict(dim=256), dict(dim_mults=(1, 2, 4, 8)), dict(dim_mults=(1, 1, 2)), dict(init_dim=256), dict(resnet_block_groups=4),
+                   dict(learned_variance=True), dict(learned_sinusoidal_cond=True), dict(random_fourier_features=True),
+                   dict(seperate_all=False, channels=65)]
+        for kw in refused:
+            with pytest.raises(NotImplementedError):
+                Unet1D(**dict(ok, **kw))
+        with pytest.raises(ValueError):
+            Unet1D(**dict(ok, channels=63))                                     # channels must equal the attribute widths when separated
+        with pytest.raises(NotImplementedError):
+            Unet1D()                                                            # the reference's own defaults: dim=256, dim_mults=(1,2,4,8)
+
+
 def test_flat_storage_keeps_module_semantics():
     import contextlib
     import io
