@@ -280,255 +280,4 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same block with HALF the global-load instructions.  The token step is issue-bound (tools/tn_probe, profiles/
-// r04_tn_probe.txt: 5156 cycles against an MFMA floor of 3072; the 24 buffer_load_dword per thread are the largest item, ~970), and
-// what a lane needs -- 8 consecutive tokens of ONE channel -- cannot be had from a wider load of one token row without dynamic register
-// selects.  But a lane can take TWO adjacent channels of each token with one 8-byte load and keep them in two statically indexed
-// register sets: an item is (channel PAIR, token octet), 192 pairs x 4 octets = 768 items for 512 threads = one full item (8 loads of 8
-// bytes, two split8) plus one HALF item (a pair x 4 tokens: 4 loads, two 4-token splits written as 8-byte LDS pieces) per thread --
-// 12 loads instead of 24 for the same bytes, the same VALU work, 12 LDS writes instead of 9.  LDS image, fragment reads, MFMA order and
-// therefore every product are those of tn_split_block; only the association of the bias-gradient partial sums differs (5 partials per
-// channel instead of 4).  Needs even leading dimensions / channel counts and 8-byte aligned operands (the caller checks; else the
-// block runs tn_split_block).
-// ---------------------------------------------------------------------------------------------------------------------
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int SMEM_X2 = 2 * STAGE + 5 * BN * 4;       // [5 partials][256 channels] f32 for the bias gradient
-
-__device__ __forceinline__ void split4(const float (&x)[4], u32x2& p1, u32x2& p2, u32x2& p3) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const float x0 = x[2 * q], x1 = x[2 * q + 1];
-        const unsigned u1 = cvt_pk_bf16(x0, x1);
-        const float r0 = x0 - bf_lo(u1), r1 = x1 - bf_hi(u1);
-        const unsigned u2 = cvt_pk_bf16(r0, r1);
-        p1[q] = u1;
-        p2[q] = u2;
-        p3[q] = cvt_pk_bf16(r0 - bf_lo(u2), r1 - bf_hi(u2));
-    }
-}
-
-__device__ __forceinline__ void tn_split_block_x2(const Prob& p, const int it, const int jt, const int split, char* smem) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave_u & 3, wk = wave_u >> 2;
-    const int n0 = jt * BN, k0 = it * BKO;
-    const long m_begin = (long)split * p.chunk;
-    const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
-    const int steps = m_end > m_begin ? (int)((m_end - m_begin + BMS - 1) / BMS) : 0;
-    const int g = lane >> 4, l15 = lane & 15;
-    const bool seg1 = k0 < p.k1;
-    const float* const xbase = seg1 ? p.a1 + k0 : p.a2 + (k0 - p.k1);
-    const long ldx = seg1 ? p.lda1 : p.lda2;
-    const int xcols = seg1 ? p.k1 - k0 : p.k1 + p.k2 - k0;
-    const float* const dbase = p.dy + n0;
-    const int dcols = p.n - n0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    long xrec = ((long)(p.m - 1) * ldx + xcols) * 4, drec = ((long)(p.m - 1) * p.ldd + dcols) * 4;
-    if (xrec > 0x7fffffffL) xrec = 0x7fffffffL;
-    if (drec > 0x7fffffffL) drec = 0x7fffffffL;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, (int)xrec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000);
-#endif
-    // full item: combo tid = og * 192 + pair (og 0..2; og 2 holds the dy pairs only); half item: combo 512 + (tid & 255), tokens
-    // 4 (tid >> 8) .. +3 of its octet.  Pair pr: dy channels 2 pr, 2 pr + 1 (pr < 128) or x channels 2 (pr - 128), +1; LDS channel = 2 pr.
-    const int f_og = tid / 192, f_pr = tid % 192;
-    const int hj = tid & 255, hf = tid >> 8;
-    const int h_og = hj < 64 ? 2 : 3, h_pr = hj < 64 ? 128 + hj : hj - 64;
-    const bool f_dy = __builtin_amdgcn_readfirstlane((wave_u * 64) % 192) < 128;                  // wave-uniform: 192 = 3 x 64
-    const bool h_dy = __builtin_amdgcn_readfirstlane(wave_u & 3) == 1 || __builtin_amdgcn_readfirstlane(wave_u & 3) == 2;
-    auto voff_of = [&](bool isdy, int pr, int tok0) {
-        const int c = isdy ? 2 * pr : 2 * (pr - 128);
-        const int cc = isdy ? (c < dcols ? c : 0) : (c < xcols ? c : 0);     // past the edge: channel 0 (valid memory, products never stored)
-        return (int)((cc + (long)tok0 * (isdy ? p.ldd : ldx)) * 4);
-    };
-    const int f_voff = voff_of(f_dy, f_pr, 8 * f_og), h_voff = voff_of(h_dy, h_pr, 8 * h_og + 4 * hf);
-    const int f_lds = 2 * f_pr * 64 + ((f_og ^ (f_pr & 3)) << 4);
-    const int h_lds = 2 * h_pr * 64 + ((h_og ^ (h_pr & 3)) << 4) + 8 * hf;
-    const long f_ld = f_dy ? p.ldd : ldx, h_ld = h_dy ? p.ldd : ldx;
-    const bool do_bias = p.bias_out != nullptr && it == 0;
-    float bs_f0 = 0.f, bs_f1 = 0.f, bs_h0 = 0.f, bs_h1 = 0.f;
-    float f0[8], f1[8], h0[4], h1[4];
-    auto load_full = [&](int step) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const long mb = m_begin + (long)step * BMS;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(f_dy ? rdy : rx, f_voff, (int)((mb + e) * f_ld * 4), 0);
-            const unsigned lo = v[0], hi = v[1];       // (bit-casting the vector element expression itself reads element 0 twice: clang)
-            f0[e] = __builtin_bit_cast(float, lo);
-            f1[e] = __builtin_bit_cast(float, hi);
-        }
-#else
-        (void)step;
-#endif
-    };
-    auto load_half = [&](int step) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const long mb = m_begin + (long)step * BMS;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(h_dy ? rdy : rx, h_voff, (int)((mb + e) * h_ld * 4), 0);
-            const unsigned lo = v[0], hi = v[1];
-            h0[e] = __builtin_bit_cast(float, lo);
-            h1[e] = __builtin_bit_cast(float, hi);
-        }
-#else
-        (void)step;
-#endif
-    };
-    auto store_full_ch = [&](const float (&x)[8], float& bsum, char* stage, int choff, bool count) {
-        if (do_bias && f_dy && count) bsum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-        bf16x8 a, b, c;
-        split8(x, a, b, c);
-        *reinterpret_cast<bf16x8*>(stage + f_lds + choff) = a;
-        *reinterpret_cast<bf16x8*>(stage + PLANE + f_lds + choff) = b;
-        *reinterpret_cast<bf16x8*>(stage + 2 * PLANE + f_lds + choff) = c;
-    };
-    auto store_half = [&](char* stage, bool count) {
-        if (do_bias && h_dy && count) {
-            bs_h0 += (h0[0] + h0[1]) + (h0[2] + h0[3]);
-            bs_h1 += (h1[0] + h1[1]) + (h1[2] + h1[3]);
-        }
-        u32x2 a, b, c;
-        split4(h0, a, b, c);
-        *reinterpret_cast<u32x2*>(stage + h_lds) = a;
-        *reinterpret_cast<u32x2*>(stage + PLANE + h_lds) = b;
-        *reinterpret_cast<u32x2*>(stage + 2 * PLANE + h_lds) = c;
-        split4(h1, a, b, c);
-        *reinterpret_cast<u32x2*>(stage + h_lds + 64) = a;
-        *reinterpret_cast<u32x2*>(stage + PLANE + h_lds + 64) = b;
-        *reinterpret_cast<u32x2*>(stage + 2 * PLANE + h_lds + 64) = c;
-    };
-
-    int xoff[4], doff[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int cx = BN + wk * 64 + b * 16 + l15, cd = wn * 64 + b * 16 + l15;
-        xoff[b] = cx * 64 + ((g ^ ((cx >> 1) & 3)) << 4);
-        doff[b] = cd * 64 + ((g ^ ((cd >> 1) & 3)) << 4);
-    }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NMMA = 24;
-    if (steps > 0) {
-        load_full(0);
-        load_half(0);
-        store_full_ch(f0, bs_f0, smem, 0, true);
-        store_full_ch(f1, bs_f1, smem, 64, true);
-        store_half(smem, true);
-        load_full(steps > 1 ? 1 : 0);
-        load_half(steps > 1 ? 1 : 0);
-    }
-    for (int s = 0; s < steps; ++s) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): my plane writes of step s are done
-        __syncthreads();
-        char* cur = smem + (s & 1) * STAGE;
-        char* nxt = smem + ((s + 1) & 1) * STAGE;
-        const bool more = s + 1 < steps;
-        const int s2 = s + 2 < steps ? s + 2 : steps - 1;
-        bf16x8 xf[4][3], df[2][3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            if (nb + 1 < 4) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
-            }
-            if (nb == 1) {
-                // the 8 loads of the full item are the oldest in flight; the half item's 4 (issued after them) may keep flying
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0f70 | 4);                                  // vmcnt(4)
-                __builtin_amdgcn_sched_barrier(0);
-                store_full_ch(f0, bs_f0, nxt, 0, more);
-            } else if (nb == 2) {
-                store_full_ch(f1, bs_f1, nxt, 64, more);
-                load_full(s2);
-            } else if (nb == 3) {
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0x0f70 | 8);                                  // vmcnt(8): the full item just re-requested
-                __builtin_amdgcn_sched_barrier(0);
-                store_half(nxt, more);
-                load_half(s2);
-            }
-            const bf16x8 (&d)[3] = df[nb & 1];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][2], d[0], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[2], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[1], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[0], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[1], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[0], acc[kb][nb], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (nb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            if (nb >= 1) {
-#pragma unroll
-                for (int q = 0; q < NMMA - 2; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMMA - 3) / (NMMA - 2), 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (nb == 3) {
-                    __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
-                    if (nb == 2) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);
-
-    float* out = p.out + (long)split * p.slab;
-    if (do_bias) {
-        // partial sums of a dy channel: full items of token octets 0, 1, 2 and the two half items of octet 3 -- five threads, fixed order
-        float* bs = reinterpret_cast<float*>(smem + 2 * STAGE);
-        __syncthreads();
-        if (f_dy) {
-            bs[f_og * BN + 2 * f_pr] = bs_f0;
-            bs[f_og * BN + 2 * f_pr + 1] = bs_f1;
-        }
-        if (h_dy) {
-            bs[(3 + hf) * BN + 2 * h_pr] = bs_h0;
-            bs[(3 + hf) * BN + 2 * h_pr + 1] = bs_h1;
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.n)
-            p.bias_out[(long)split * p.bias_slab + n0 + tid] = (bs[tid] + bs[BN + tid]) + (bs[2 * BN + tid] + (bs[3 * BN + tid] + bs[4 * BN + tid]));
-    }
-    const bool vec = (p.ldo & 3) == 0 && (p.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int j = n0 + wn * 64 + nb * 16 + l15;
-        if (j >= p.n) continue;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int i = k0 + wk * 64 + kb * 16 + 4 * g;
-            if (vec && i + 3 < p.kvalid) {
-                *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = acc[kb][nb];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[kb][nb][e];
-            }
-        }
-    }
-}
-
 }  // namespace dsc_tn_split

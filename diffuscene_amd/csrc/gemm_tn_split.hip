@@ -3,10 +3,6 @@
 // issue slots), which the other backward kernels of train.hip should not inherit.
 #include "gemm_tn_split.h"
 
-#ifndef DSC_TN_X2
-#define DSC_TN_X2 1          // (0: the round-4 dword staging everywhere -- same-box A/B builds)
-#endif
-
 // The same grouped weight-gradient launch on the bf16 matrix cores (gemm_tn_split.h: operands split exactly into three bf16 pieces,
 // six products, f32 accumulation -- error vs f64 <= the f32-MFMA kernel's, ~1.6x faster).  Tiles are 256 (n) x 128 (k), addressed
 // through the host's block map (below); the slab reduction is the f32 form's (128 x 128 tiles, tile0).
@@ -19,7 +15,7 @@
 // blocks: 1632 -> 1564 us (-4.2 %; all strips hot in every L2: 1520).
 __global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc_tn_group* __restrict__ groups, const int2* __restrict__ block_map,
                                                                        const int splits, float* __restrict__ workspace) {
-    __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::SMEM_X2];
+    __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::SMEM];
     const int2 gt = block_map[blockIdx.x];
     if (gt.x < 0) return;
     const dsc_tn_group g = groups[gt.x];
@@ -38,12 +34,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc
         p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
         p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
     }
-    // 8-byte staging loads (two adjacent channels per lane, half the load instructions: gemm_tn_split.h, round 5) wherever the group's
-    // operands allow them; odd leading dimensions / channel counts or 4-byte aligned views keep the dword form (block-uniform choice)
-    const bool x2 = DSC_TN_X2 && (((g.lda1 | g.lda2 | g.ldd) & 1) == 0) && (((g.n | g.k1 | g.k2) & 1) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(g.a1) | reinterpret_cast<uintptr_t>(g.a2) | reinterpret_cast<uintptr_t>(g.dy)) & 7) == 0;
-    if (x2) dsc_tn_split::tn_split_block_x2(p, local % ktiles, local / ktiles, split, smem);
-    else dsc_tn_split::tn_split_block<0>(p, local % ktiles, local / ktiles, split, smem);
+    dsc_tn_split::tn_split_block<0>(p, local % ktiles, local / ktiles, split, smem);
 }
 
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
