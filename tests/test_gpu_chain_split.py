@@ -178,6 +178,8 @@ def test_two_hundred_step_chain_at_b256(golden_dir, tmp_path):
             del net, diff, eng, plan
     finally:
         _lib.set_gemm_arithmetic(prev)
+    # measured on MI355X (profiles/r05_parity.txt): 1.75e-7 norm-relative, 1.4e-6 max abs over the 200 steps -- an order of magnitude BELOW
+    # either arithmetic's distance from the CPU reference (2.2e-6 / 2.9e-5 element-wise): the chain's drift from the reference is not the split's
     a, b = results["split"].double(), results["f32"].double()
     rel = float((a - b).norm() / b.norm())
     worst = float((a - b).abs().max())
@@ -185,4 +187,4 @@ def test_two_hundred_step_chain_at_b256(golden_dir, tmp_path):
     if log:
         with open(log, "a") as f:
             f.write("B=256 T=%d chain, |split - f32|: %.3e norm-relative, %.3e max abs\n" % (T, rel, worst))
-    assert rel < 2e-5, "the two arithmetics drifted apart over the chain: %.3e norm-relative (max abs %.3e)" % (rel, worst)
+    assert rel < 2e-6, "the two arithmetics drifted apart over the chain: %.3e norm-relative (max abs %.3e)" % (rel, worst)
