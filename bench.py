@@ -484,7 +484,7 @@ def _cpu_info():
     return model, phys
 
 
-def cpu_baseline(spec, mode):
+def cpu_baseline(spec, mode, sweep=False):
     """The oracle (CPU restatement of the reference path, kind 'port', pinned against the real reference by
     tests/test_oracle.py) timed on this box's host cores: FULL-batch steps of the same workload -- sampling step =
     Unet1D forward + posterior step; training step = q_sample, forward, p_losses incl. IoU, backward,
@@ -536,52 +536,58 @@ def cpu_baseline(spec, mode):
         opt.step()
 
     legs = {"sample": [sample_step], "train": [train_step], "both": [sample_step, train_step]}[mode]
-    # Host thread count: chosen PER STEP KIND (the forward-only sampling step and the forward+backward+Adam training step peak at different
-    # counts; one shared count made the sampling rate move 0.9-1.7 steps/s between boxes in round 4) by a sweep on a quarter batch with
-    # three repeats per count (minimum of the three: a stray slow run must not pick the count).
+    # Host thread count.  Round 4 picked it with a short sweep on a QUARTER batch, which made the reported rate move 0.16-1.7 steps/s
+    # between runs: the quarter batch peaks at 16 threads with 0.28 s per sampling step, while the FULL-batch step -- the batch the metric
+    # is quoted on -- takes 4.5-5.9 s on the same box at any count from 8 to 32 and 10.8 s at 64 (a full-batch sweep per step kind,
+    # profiles/r05_cpu_baseline_sweep.txt: sampling 5.9 / 5.7 / 6.1 / 10.8 s, training 13.2 / 12.8 / 15.9 / 26.7 s at 8 / 16 / 32 / 64
+    # threads).  The optimum is flat and the same for both step kinds, so the count is FIXED at 16 (DSC_CPU_BASELINE_THREADS overrides;
+    # `--cpu-sweep` repeats the full-batch sweep, ~5 minutes) and the bounded sample is a handful of full-batch steps (~1 minute).
     ncpu = os.cpu_count() or 1
-    q = slice(0, max(B // 4, 1))
-    counts = sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)})
-    times, threads_of, sweep = {}, {}, {}
+    times, threads_of, sweep_log = {}, {}, {}
+    fixed = min(int(os.environ.get("DSC_CPU_BASELINE_THREADS", "16")), ncpu)
     for f in legs:
-        best = None
-        for th in counts:
-            torch.set_num_threads(th)
-            f(q)                                    # warm-up at this thread count
-            d = None
-            for _ in range(3):
-                t1 = time.perf_counter()
-                f(q)
-                e = time.perf_counter() - t1
-                d = e if d is None else min(d, e)
-            sweep.setdefault(f.__name__, {})[th] = round(d, 4)
-            log("cpu_baseline: %s, %d threads -> %.3f s on %d scenes (min of 3)" % (f.__name__, th, d, q.stop))
-            if best is None or d < best[1]:
-                best = (th, d)
-            if d > 2.0 * best[1]:
-                break                               # oversubscribed: more threads only get slower
+        best = (fixed, None)
+        if sweep:
+            best = None
+            for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+                torch.set_num_threads(th)
+                f()                                 # warm-up at this thread count
+                d = None
+                for _ in range(2 if f is sample_step else 1):
+                    t1 = time.perf_counter()
+                    f()
+                    e = time.perf_counter() - t1
+                    d = e if d is None else min(d, e)
+                sweep_log.setdefault(f.__name__, {})[th] = round(d, 4)
+                log("cpu_baseline: %s, %d threads -> %.3f s at the full batch" % (f.__name__, th, d))
+                if best is None or d < best[1]:
+                    best = (th, d)
+                if d > 1.5 * best[1]:
+                    break                           # past the optimum: more threads only get slower
         threads_of[f.__name__] = best[0]
         torch.set_num_threads(best[0])
         f()                                         # warm-up at full batch
         per_step, t0 = [], time.perf_counter()
+        n_min = 3 if f is sample_step else 2
         while True:
             t1 = time.perf_counter()
             f()
             per_step.append(time.perf_counter() - t1)
-            if len(per_step) >= 3 and (time.perf_counter() - t0 > 10.0 or len(per_step) >= 20):
+            if len(per_step) >= n_min and (time.perf_counter() - t0 > 12.0 or len(per_step) >= 20):
                 break
         per_step.sort()
-        times[f.__name__] = (per_step[len(per_step) // 2], len(per_step))          # median of >= 3 full-batch steps
+        times[f.__name__] = (per_step[len(per_step) // 2], len(per_step))          # median of the timed full-batch steps
+        log("cpu_baseline: %s, %d threads: median %.3f s over %d full-batch steps" % (f.__name__, best[0], times[f.__name__][0], len(per_step)))
     threads = max(threads_of.values())
     per = sum(v[0] for v in times.values()) / len(times)            # 'both': mean of the two step kinds (1:1 mix)
     model, phys = _cpu_info()
     out = {"value": round(1.0 / per, 4), "unit": "steps/s", "cores": threads, "kind": "port",
            "why_port": "the reference tree (/root/reference) does not exist on the GPU box, so its modules cannot be timed here; the "
                        "port is the same PyTorch-CPU ops in the same order (oracle/ref_torch.py), pinned to the real modules as below",
-           "statistic": "median of >= 3 full-batch steps per step kind, each kind at the thread count its own sweep (quarter batch, min of 3 "
-                        "repeats per count) found fastest; cores = the larger of the two",
+           "statistic": "median of >= 3 (sampling) / >= 2 (training) full-batch steps after a warm-up step, at a fixed thread count (the "
+                        "full-batch optimum is flat from 8 to 32 threads for both step kinds: profiles/r05_cpu_baseline_sweep.txt)",
            "threads_per_step_kind": {k.replace("_step", ""): v for k, v in threads_of.items()},
-           "thread_sweep_seconds_quarter_batch": {k.replace("_step", ""): v for k, v in sweep.items()},
+           "thread_sweep_seconds_full_batch": {k.replace("_step", ""): v for k, v in sweep_log.items()} or None,
            "pinned_by": "tests/test_oracle.py (the port vs the real reference modules, <= 2e-5; schedule tables bit-exact) and "
                         "tests/golden/*.npz (outputs of the real reference, regenerated by oracle/make_golden*.py)",
            "sample": "full-batch oracle steps (B=%d, N=%d), median: %s; train = q_sample + fwd + p_losses(IoU) + bwd + "
@@ -742,6 +748,7 @@ def main():
                     help="weak (default): the config's batch per GPU; strong: the config's batch is the GLOBAL batch, split over "
                          "the ranks (SURVEY.md 8e: B=256 global = 32 scenes per GPU at 8 GPUs, communication-dominated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sweep", action="store_true", help="cpu_baseline: sweep the host thread count on the full-batch steps (~5 minutes)")
     ap.add_argument("--no-full-loop", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` / `exact_f32` blocks the default single-GPU run appends after the headline line's "
@@ -948,7 +955,7 @@ def main():
             out["model_executed_tflops"] = round(out["model_tflops"] * mult, 1)
             out["model_frac_of_bf16_mfma_peak"] = round(out["model_tflops"] * mult / PEAK_BF16_MFMA_TFLOPS, 4)
         if not args.no_cpu_baseline and ws == 1:          # the CPU baseline is a single-GPU-run figure (rank 0, N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(spec, args.mode)
+            out["cpu_baseline"] = cpu_baseline(spec, args.mode, sweep=args.cpu_sweep)
         default_run = (ws == 1 and args.config == "living80" and args.mode == "both" and not args.batch and not args.objects
                        and args.scaling == "weak")
         if default_run and not args.no_other_configs:
