@@ -183,7 +183,8 @@ class HipBackend:
         return _mat(t, "plan tensor")
 
     def _call(self, name, *args, keep=()):
-        self.keep.append(keep)
+        from .engine import _own
+        self.keep.append(_own(keep))          # parameters as aliases of their storage: the launch's pointers stay owned by the plan
         return (self.lib.fn(name), args, name)
 
     def finalize(self):
