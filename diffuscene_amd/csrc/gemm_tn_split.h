@@ -280,4 +280,287 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same block with PRODUCER and CONSUMER waves.  An MFMA blocks its wave: in tn_split_block every wave interleaves its
+// 96 MFMAs per step with its own share of the staging (24 loads, 132 VALU of operand split, 9 LDS writes), and the round-4 probes
+// showed those costs ADD to the MFMA time (5156 cycles per step against an MFMA floor of 3072) however they are slotted -- the two
+// waves of a SIMD walk in phase.  Here the block has 12 waves: waves 0-7 are the round-4 consumers (fragment reads + MFMAs only: same
+// wave tiles, same fragment offsets, same MFMA order, hence bit-identical dW), waves 8-11 do ALL the staging of the block (the
+// same (channel, token octet) items, six per lane and step instead of three, the same LDS image, the same per-item bias partial sums
+// in the same LDS slots, hence bit-identical bias gradients) one step ahead, and the only thing the two kinds share is the one barrier
+// per step.  A SIMD holds two consumers and one producer: the producer's VALU / VMEM / LDS-write instructions issue in the cycles
+// the matrix pipe is busy with a consumer's MFMA.  168 VGPRs per wave (three waves per SIMD).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int NPW = 4, TP = NPW * 64, T_WS = T + TP;  // producer waves / threads; block size 768
+constexpr int NITP = COLS * 4 / TP;                   // 6 items per producer lane and step (dword form)
+constexpr int PAIRS = COLS / 2, NITX = PAIRS * 4 / TP;// 192 channel pairs x 4 token octets = 3 items per producer lane and step (8-byte form)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, const int jt, const int split, char* smem, const bool x2) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = jt * BN, k0 = it * BKO;
+    const long m_begin = (long)split * p.chunk;
+    const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
+    const int steps = m_end > m_begin ? (int)((m_end - m_begin + BMS - 1) / BMS) : 0;
+    const bool do_bias = p.bias_out != nullptr && it == 0;
+    float* const bs = reinterpret_cast<float*>(smem + 2 * STAGE);
+
+    if (wave_u >= NW) {
+        // ------------------------------------------------------------------------------------------------ producers
+#ifdef DSC_TN_PRIO
+        __builtin_amdgcn_s_setprio(DSC_TN_PRIO);
+#endif
+        const int pt = tid - T;                           // 0..255
+        const int pw = wave_u - NW;
+        const bool seg1 = k0 < p.k1;
+        const float* const xbase = seg1 ? p.a1 + k0 : p.a2 + (k0 - p.k1);
+        const long ldx = seg1 ? p.lda1 : p.lda2;
+        const int xcols = seg1 ? p.k1 - k0 : p.k1 + p.k2 - k0;
+        const float* const dbase = p.dy + n0;
+        const int dcols = p.n - n0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        long xrec = ((long)(p.m - 1) * ldx + xcols) * 4, drec = ((long)(p.m - 1) * p.ldd + dcols) * 4;
+        if (xrec > 0x7fffffffL) xrec = 0x7fffffffL;
+        if (drec > 0x7fffffffL) drec = 0x7fffffffL;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, (int)xrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000);
+#endif
+        if (x2) {
+            // 8-byte loads, TWO steps of lead.  The probes of this form (producers idle: 3830 us for the launch = the MFMA floor; staging
+            // without loads: 4459; with loads one step ahead: 6167) showed the producers waiting for their loads: a step of the consumers
+            // is 1.5 us, less than the memory latency under this kernel's own traffic.  An item is a channel PAIR x a token octet (8 loads
+            // of 8 bytes, both channels of a token at once: 24 loads per lane and step instead of 48, so that two steps in flight fit the
+            // 6-bit vmcnt), three items per lane and step, two register sets alternating by step.
+            int ivoff[NITX], ildso[NITX], bslot[NITX];
+            bool isdy[NITX];
+#pragma unroll
+            for (int u = 0; u < NITX; ++u) {
+                const int t = u * TP + pt, pr = t % PAIRS, og = t / PAIRS;
+                isdy[u] = __builtin_amdgcn_readfirstlane((u * TP + pw * 64) % PAIRS) < BN / 2;     // wave-uniform: 192 = 3 x 64
+                const int c = isdy[u] ? 2 * pr : 2 * pr - BN;                                       // channel inside its operand
+                const int cc = isdy[u] ? (c < dcols ? c : 0) : (c < xcols ? c : 0);                 // past the edge: channel 0 (never stored)
+                ivoff[u] = (int)((cc + 8L * og * (isdy[u] ? p.ldd : ldx)) * 4);
+                ildso[u] = 2 * pr * 64 + ((og ^ (pr & 3)) << 4);                                    // LDS channel 2 pr; 2 pr + 1 sits 64 bytes on
+                bslot[u] = og * BN + 2 * pr;
+            }
+            float bsum[NITX][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            float ld[2][NITX][2][8];                          // [register set][item][channel of the pair][token]
+            auto load_item = [&](auto setc, int u, int step) {
+                constexpr int S = decltype(setc)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+                const long mb = m_begin + (long)step * BMS;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(isdy[u] ? rdy : rx, ivoff[u], (int)((mb + e) * (isdy[u] ? p.ldd : ldx) * 4), 0);
+                    const unsigned lo = v[0], hi = v[1];      // (bit-casting the element expression itself reads element 0 twice: clang)
+                    ld[S][u][0][e] = __builtin_bit_cast(float, lo);
+                    ld[S][u][1][e] = __builtin_bit_cast(float, hi);
+                }
+#else
+                (void)u; (void)step;
+#endif
+            };
+            auto store_item = [&](auto setc, int u, char* stage, bool count) {
+                constexpr int S = decltype(setc)::value;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float (&x)[8] = ld[S][u][h];
+                    if (do_bias && isdy[u] && count) bsum[u][h] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                    bf16x8 a, b, c;
+                    split8(x, a, b, c);
+                    *reinterpret_cast<bf16x8*>(stage + ildso[u] + 64 * h) = a;
+                    *reinterpret_cast<bf16x8*>(stage + PLANE + ildso[u] + 64 * h) = b;
+                    *reinterpret_cast<bf16x8*>(stage + 2 * PLANE + ildso[u] + 64 * h) = c;
+                }
+            };
+            using S0 = std::integral_constant<int, 0>;
+            using S1 = std::integral_constant<int, 1>;
+            auto clampi = [&](int st) { return st < steps ? st : steps - 1; };
+            if (steps > 0) {
+#pragma unroll
+                for (int u = 0; u < NITX; ++u) load_item(S0{}, u, 0);
+#pragma unroll
+                for (int u = 0; u < NITX; ++u) store_item(S0{}, u, smem, true);
+#pragma unroll
+                for (int u = 0; u < NITX; ++u) load_item(S1{}, u, clampi(1));
+#pragma unroll
+                for (int u = 0; u < NITX; ++u) load_item(S0{}, u, clampi(2));
+            }
+            // step s: the data of step s + 1 (set (s + 1) & 1, requested two steps ago) goes to the other stage; its registers take step s + 3
+            auto pstep = [&](auto setc, int s) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): my plane writes of step s are done
+                __syncthreads();                          // the consumers have left the other stage
+                char* nxt = smem + ((s + 1) & 1) * STAGE;
+                const bool more = s + 1 < steps;
+                const int s3 = clampi(s + 3);
+#pragma unroll
+                for (int u = 0; u < NITX; ++u) {
+                    // younger than item u of this set: the rest of the set, the whole other set, and what was re-requested so far: 40 loads
+                    __builtin_amdgcn_s_waitcnt(0x0f70 | (40 & 15) | ((40 >> 4) << 14));
+                    store_item(setc, u, nxt, more);
+#ifdef DSC_TN_WS_SAMEROWS
+                    load_item(setc, u, 0);            // tools only: same instruction stream, every load an L1 hit (results are garbage)
+#else
+                    load_item(setc, u, s3);
+#endif
+                }
+            };
+            for (int s = 0; s < steps; s += 2) {
+                pstep(S1{}, s);
+                if (s + 1 < steps) pstep(S0{}, s + 1);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            if (do_bias) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < NITX; ++u)
+                    if (isdy[u]) { bs[bslot[u]] = bsum[u][0]; bs[bslot[u] + 1] = bsum[u][1]; }
+                __syncthreads();
+            }
+            return;
+        }
+        // dword loads, one step of lead: operands with odd leading dimensions / channel counts or 4-byte aligned views
+        int ivoff[NITP], ildso[NITP], bslot[NITP];
+        bool isdy[NITP];
+#pragma unroll
+        for (int u = 0; u < NITP; ++u) {
+            const int t = u * TP + pt, c = t % COLS, og = t / COLS;
+            isdy[u] = __builtin_amdgcn_readfirstlane((u * TP + pw * 64) % COLS) < BN;        // wave-uniform: 384 = 6 x 64
+            const int cc = isdy[u] ? (c < dcols ? c : 0) : (c - BN < xcols ? c - BN : 0);
+            ivoff[u] = (int)((cc + 8L * og * (isdy[u] ? p.ldd : ldx)) * 4);
+            ildso[u] = c * 64 + ((og ^ ((c >> 1) & 3)) << 4);
+            bslot[u] = og * BN + c;
+        }
+        float bsum[NITP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float ld[NITP][8];
+        auto load_item = [&](int u, int step) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const long mb = m_begin + (long)step * BMS;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                ld[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isdy[u] ? rdy : rx, ivoff[u],
+                                                                                           (int)((mb + e) * (isdy[u] ? p.ldd : ldx) * 4), 0));
+#else
+            (void)u; (void)step;
+#endif
+        };
+        auto store_item = [&](int u, char* stage, bool count) {
+            if (do_bias && isdy[u] && count) bsum[u] += ((ld[u][0] + ld[u][1]) + (ld[u][2] + ld[u][3])) + ((ld[u][4] + ld[u][5]) + (ld[u][6] + ld[u][7]));
+            bf16x8 a, b, c;
+            split8(ld[u], a, b, c);
+            *reinterpret_cast<bf16x8*>(stage + ildso[u]) = a;
+            *reinterpret_cast<bf16x8*>(stage + PLANE + ildso[u]) = b;
+            *reinterpret_cast<bf16x8*>(stage + 2 * PLANE + ildso[u]) = c;
+        };
+        if (steps > 0) {
+#pragma unroll
+            for (int u = 0; u < NITP; ++u) load_item(u, 0);
+#pragma unroll
+            for (int u = 0; u < NITP; ++u) store_item(u, smem, true);
+#pragma unroll
+            for (int u = 0; u < NITP; ++u) load_item(u, steps > 1 ? 1 : 0);
+        }
+        for (int s = 0; s < steps; ++s) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): my plane writes of step s are done
+            __syncthreads();                              // the consumers have left the other stage
+            char* nxt = smem + ((s + 1) & 1) * STAGE;
+            const bool more = s + 1 < steps;
+            const int s2 = s + 2 < steps ? s + 2 : steps - 1;
+#pragma unroll
+            for (int u = 0; u < NITP; ++u) {
+                __builtin_amdgcn_s_waitcnt(0x0f70 | (((NITP - 1) * 8) & 15) | ((((NITP - 1) * 8) >> 4) << 14));     // vmcnt(40): item u has landed
+                store_item(u, nxt, more);
+                load_item(u, s2);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        if (do_bias) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < NITP; ++u)
+                if (isdy[u]) bs[bslot[u]] = bsum[u];
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- consumers (waves 0..7)
+    const int wn = wave_u & 3, wk = wave_u >> 2;
+    const int g = lane >> 4, l15 = lane & 15;
+    int xoff[4], doff[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int cx = BN + wk * 64 + b * 16 + l15, cd = wn * 64 + b * 16 + l15;
+        xoff[b] = cx * 64 + ((g ^ ((cx >> 1) & 3)) << 4);
+        doff[b] = cd * 64 + ((g ^ ((cd >> 1) & 3)) << 4);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < steps; ++s) {
+        __syncthreads();                                  // stage s & 1 is complete
+        char* cur = smem + (s & 1) * STAGE;
+        bf16x8 xf[4][3], df[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb + 1 < 4) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
+            }
+            const bf16x8 (&d)[3] = df[nb & 1];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][2], d[0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[2], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[0], acc[kb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (nb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 23, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float* out = p.out + (long)split * p.slab;
+    if (do_bias) {
+        __syncthreads();                                  // (the producers write their partial sums between these two)
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.n)
+            p.bias_out[(long)split * p.bias_slab + n0 + tid] = (bs[tid] + bs[BN + tid]) + (bs[2 * BN + tid] + bs[3 * BN + tid]);
+    }
+    const bool vec = (p.ldo & 3) == 0 && (p.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int j = n0 + wn * 64 + nb * 16 + l15;
+        if (j >= p.n) continue;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int i = k0 + wk * 64 + kb * 16 + 4 * g;
+            if (vec && i + 3 < p.kvalid) {
+                *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = acc[kb][nb];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[kb][nb][e];
+            }
+        }
+    }
+}
+
 }  // namespace dsc_tn_split

@@ -3,6 +3,10 @@
 // issue slots), which the other backward kernels of train.hip should not inherit.
 #include "gemm_tn_split.h"
 
+#ifndef DSC_TN_WS
+#define DSC_TN_WS 1          // 1: producer / consumer waves (12 waves per block, round 5); 0: the round-4 block (same-box A/B builds)
+#endif
+
 // The same grouped weight-gradient launch on the bf16 matrix cores (gemm_tn_split.h: operands split exactly into three bf16 pieces,
 // six products, f32 accumulation -- error vs f64 <= the f32-MFMA kernel's, ~1.6x faster).  Tiles are 256 (n) x 128 (k), addressed
 // through the host's block map (below); the slab reduction is the f32 form's (128 x 128 tiles, tile0).
@@ -37,6 +41,36 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc
     dsc_tn_split::tn_split_block<0>(p, local % ktiles, local / ktiles, split, smem);
 }
 
+// The same launch with producer and consumer waves (gemm_tn_split.h, tn_split_block_ws): 768 threads, identical results.
+__global__ __launch_bounds__(dsc_tn_split::T_WS, 1) void gemm_tn_split_grouped_ws_kernel(const dsc_tn_group* __restrict__ groups,
+                                                                                         const int2* __restrict__ block_map, const int splits,
+                                                                                         float* __restrict__ workspace) {
+    __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::SMEM];
+    const int2 gt = block_map[blockIdx.x];
+    if (gt.x < 0) return;
+    const dsc_tn_group g = groups[gt.x];
+    const int K = g.k1 + g.k2;
+    const int ktiles = (K + 127) / 128;
+    const int local = gt.y;
+    const int split = blockIdx.y;
+    dsc_tn_split::Prob p;
+    p.a1 = g.a1; p.lda1 = g.lda1; p.k1 = g.k1; p.a2 = g.a2; p.lda2 = g.lda2; p.k2 = g.k2; p.dy = g.dy; p.ldd = g.ldd;
+    p.m = g.m; p.n = g.n; p.kvalid = g.kvalid;
+    p.chunk = ((g.m + splits - 1) / splits + 31) / 32 * 32;
+    if (splits == 1) {
+        p.out = g.out; p.ldo = g.ldo; p.bias_out = g.dbias; p.slab = 0; p.bias_slab = 0;
+    } else {
+        const long wslab = (long)g.n * g.kvalid;
+        p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
+        p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
+    }
+    // 8-byte staging loads with two steps of lead wherever the group's operands allow them (even leading dimensions and channel
+    // counts, 8-byte aligned bases: every activation of the denoiser); block-uniform
+    const bool x2 = (((g.lda1 | g.lda2 | g.ldd) & 1) == 0) && (((g.n | g.k1 | g.k2) & 1) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(g.a1) | reinterpret_cast<uintptr_t>(g.a2) | reinterpret_cast<uintptr_t>(g.dy)) & 7) == 0;
+    dsc_tn_split::tn_split_block_ws(p, local % ktiles, local / ktiles, split, smem, x2);
+}
+
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
                                              const int32_t* block_map_dev, int32_t blocks, int32_t splits, float* workspace,
                                              int64_t workspace_floats, int64_t workspace_needed, dsc_stream_t stream) {
@@ -45,8 +79,13 @@ extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int
     if (splits > 1 && (!workspace || workspace_floats < workspace_needed || workspace_needed < 1)) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DSC_CLEAR_STALE_ERROR();
+#if DSC_TN_WS
+    hipLaunchKernelGGL(gemm_tn_split_grouped_ws_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(dsc_tn_split::T_WS), 0, s, groups_dev,
+                       reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
+#else
     hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(512), 0, s, groups_dev,
                        reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
+#endif
     DSC_LAUNCH_CHECK();
     if (splits > 1) return dsc_launch_reduce_grouped(groups_dev, count, total_tiles, splits, workspace, s);
     return 0;
