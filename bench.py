@@ -784,12 +784,23 @@ def main():
                          "plain shell so that bench.py spawns the ranks itself)" % (args.gpus, ws, args.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if ws > 1:
+    # DSC_BENCH_DDP_REHEARSAL=1 (one GPU): run the MULTI-GPU code path of this script -- process group, broadcast, the three-schedule
+    # comparison, reducer, MAX all-reduces -- on a world-1 RCCL group with the reducer forced on, so that every line the driver's
+    # 8-GPU run executes has executed on hardware before (no multi-GPU box was ever available to the builder).  `mw` = what the helpers
+    # that branch on "more than one rank" see.
+    rehearsal = ws == 1 and os.environ.get("DSC_BENCH_DDP_REHEARSAL") == "1" and not (args.ddp_selftest or args.side_line)
+    mw = 2 if rehearsal else ws
+    if mw > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        with phase("init_process_group (RCCL)", ws):
-            dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=240))
-    rank = dist.get_rank() if ws > 1 else 0
+        with phase("init_process_group (RCCL)", mw):
+            if rehearsal:
+                os.environ["DSC_DDP_FORCE"] = "1"
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, device_id=device,
+                                        timeout=datetime.timedelta(seconds=240))
+            else:
+                dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=240))
+    rank = dist.get_rank() if mw > 1 else 0
     if args.ddp_selftest:
         if ws != 1:
             raise SystemExit("bench.py: --ddp-selftest is a single-GPU run")
@@ -812,29 +823,29 @@ def main():
         spec["batch"] //= ws
     B, N = spec["batch"], spec["objects"]
     log("building model (%s: B=%d per GPU, N=%d, %s scaling)" % (args.config, B, N, args.scaling))
-    with phase("build_model", ws):
+    with phase("build_model", mw):
         model, cfg = build_model(spec, device)
-    if ws > 1:
+    if mw > 1:
         from diffuscene_amd import ddp
-        with phase("broadcast_parameters (first RCCL collective)", ws):
+        with phase("broadcast_parameters (first RCCL collective)", mw):
             ddp.broadcast_parameters(model)         # every replica starts from rank 0's weights
-            barrier(ws)                             # no collective in flight while the sampling graph is being captured
+            barrier(mw)                             # no collective in flight while the sampling graph is being captured
     log("model on device")
     n_s = {"both": (args.steps + 1) // 2, "sample": args.steps, "train": 0}[args.mode]
     n_t = args.steps - n_s
-    with phase("capture sampling graph", ws):
+    with phase("capture sampling graph", mw):
         sr = SampleRunner(spec, model, device, seed=rank) if n_s else None
         if sr:
             sr.run(args.warmup)
             sr.reset()
     schedules, chosen = None, None
-    if ws > 1 and n_t:
+    if mw > 1 and n_t:
         # one driver run compares the three data-parallel schedules on the node; the headline regions use the fastest
-        schedules, chosen = compare_ddp_schedules(spec, model, device, rank, ws)
+        schedules, chosen = compare_ddp_schedules(spec, model, device, rank, mw)
         if chosen is None:
             raise SystemExit("bench.py: no data-parallel schedule ran on all ranks: %s" % json.dumps(schedules))
         os.environ["DSC_DDP_FLUSH"] = chosen
-    with phase("training warm-up (eager step, graph capture, first all-reduces)", ws):
+    with phase("training warm-up (eager step, graph capture, first all-reduces)", mw):
         tr = TrainRunner(spec, model, device, rank) if n_t else None
         if tr:
             tr.run(args.warmup)
@@ -854,15 +865,15 @@ def main():
     for _ in range(3):
         if sr:
             sr.reset()
-        regions.append(timed(ws, region))
+        regions.append(timed(mw, region))
     log("timed regions: %s s for %d steps each (%d sample + %d train)" % (", ".join("%.3f" % r for r in regions), args.steps, n_s, n_t))
     parts = {}
     if args.mode == "both":          # the two rates separately (outside the headline regions), median of three as well
         ps, pt = [], []
         for _ in range(3):
             sr.reset()
-            ps.append(timed(ws, lambda: sr.run(n_s)) / n_s)
-            pt.append(timed(ws, lambda: tr.run(n_t)) / max(n_t, 1))
+            ps.append(timed(mw, lambda: sr.run(n_s)) / n_s)
+            pt.append(timed(mw, lambda: tr.run(n_t)) / max(n_t, 1))
         parts = {"sample": ps, "train": pt}
     full = None
     if sr and not args.no_full_loop:
@@ -872,7 +883,7 @@ def main():
         log("full 1000-step loop: %.3f s" % full)
     flat = regions + parts.get("sample", [0.0] * 3) + parts.get("train", [0.0] * 3) + [full or 0.0]
     tmax = torch.tensor(flat, device=device, dtype=torch.float64)
-    if ws > 1:
+    if mw > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = [float(v) for v in tmax.tolist()]
     regions = tmax[0:3]
@@ -882,7 +893,7 @@ def main():
     if full is not None:
         full = tmax[9]
     comm = None
-    if ws > 1 and tr:
+    if mw > 1 and tr:
         from diffuscene_amd import ddp
         comm = ddp.measure_allreduce(model, reps=5)         # the gradient exchange alone (no compute to hide behind)
 
@@ -970,8 +981,10 @@ def main():
             if _lib.split_enabled():
                 out["exact_f32"] = side_line_child("living80:f32")
                 log("exact_f32 done")
+        if rehearsal:
+            out["ddp_rehearsal"] = "world-1 RCCL group, reducer forced on: the multi-GPU code path of this script on ONE GPU (not a scaling number)"
         print(json.dumps(out), flush=True)
-    if ws > 1:
+    if mw > 1:
         dist.barrier()
         dist.destroy_process_group()
 
