@@ -291,12 +291,17 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
 // per step.  A SIMD holds two consumers and one producer: the producer's VALU / VMEM / LDS-write instructions issue in the cycles
 // the matrix pipe is busy with a consumer's MFMA.  168 VGPRs per wave (three waves per SIMD).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int NPW = 4, TP = NPW * 64, T_WS = T + TP;  // producer waves / threads; block size 768
+constexpr int NPW = 4, TP = NPW * 64;                 // producer waves / threads
 constexpr int NITP = COLS * 4 / TP;                   // 6 items per producer lane and step (dword form)
 constexpr int PAIRS = COLS / 2, NITX = PAIRS * 4 / TP;// 192 channel pairs x 4 token octets = 3 items per producer lane and step (8-byte form)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// NCW = consumer waves: 8 (wave tile 64 n x 64 k, the round-4 tiles; 768 threads) or 4 (wave tile 64 n x 128 k: the dY fragments of
+// all four n blocks stay in registers and the x fragments stream per k block -- 36 instead of 48 fragment reads per 192 MFMAs, i.e.
+// 144 instead of 196 KB of LDS reads per step and CU; 512 threads).  Every accumulator sees the same six products in the same order.
+template <int NCW>
 __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, const int jt, const int split, char* smem, const bool x2) {
+    static_assert(NCW == 8 || NCW == 4, "8 or 4 consumer waves");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = jt * BN, k0 = it * BKO;
@@ -306,13 +311,13 @@ __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, c
     const bool do_bias = p.bias_out != nullptr && it == 0;
     float* const bs = reinterpret_cast<float*>(smem + 2 * STAGE);
 
-    if (wave_u >= NW) {
+    if (wave_u >= NCW) {
         // ------------------------------------------------------------------------------------------------ producers
 #ifdef DSC_TN_PRIO
         __builtin_amdgcn_s_setprio(DSC_TN_PRIO);
 #endif
-        const int pt = tid - T;                           // 0..255
-        const int pw = wave_u - NW;
+        const int pt = tid - NCW * 64;                    // 0..255
+        const int pw = wave_u - NCW;
         const bool seg1 = k0 < p.k1;
         const float* const xbase = seg1 ? p.a1 + k0 : p.a2 + (k0 - p.k1);
         const long ldx = seg1 ? p.lda1 : p.lda2;
@@ -485,55 +490,96 @@ __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, c
         return;
     }
 
-    // ---------------------------------------------------------------------------------------------------- consumers (waves 0..7)
-    const int wn = wave_u & 3, wk = wave_u >> 2;
+    // ---------------------------------------------------------------------------------------------------- consumers
+    constexpr int KBW = 32 / NCW;                          // 16-channel k blocks per wave: 4 (64 k) or 8 (128 k)
+    const int wn = wave_u & 3, wk = wave_u >> 2;           // NCW == 4: wk == 0
     const int g = lane >> 4, l15 = lane & 15;
-    int xoff[4], doff[4];
+    int xoff[KBW], doff[4];
+#pragma unroll
+    for (int b = 0; b < KBW; ++b) {
+        const int cx = BN + wk * 64 + b * 16 + l15;
+        xoff[b] = cx * 64 + ((g ^ ((cx >> 1) & 3)) << 4);
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int cx = BN + wk * 64 + b * 16 + l15, cd = wn * 64 + b * 16 + l15;
-        xoff[b] = cx * 64 + ((g ^ ((cx >> 1) & 3)) << 4);
+        const int cd = wn * 64 + b * 16 + l15;
         doff[b] = cd * 64 + ((g ^ ((cd >> 1) & 3)) << 4);
     }
-    f32x4 acc[4][4];
+    f32x4 acc[KBW][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < KBW; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < steps; ++s) {
         __syncthreads();                                  // stage s & 1 is complete
         char* cur = smem + (s & 1) * STAGE;
-        bf16x8 xf[4][3], df[2][3];
+        if constexpr (NCW == 8) {
+            bf16x8 xf[4][3], df[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
+            for (int pl = 0; pl < 3; ++pl) df[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[0]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            if (nb + 1 < 4) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
-            }
-            const bf16x8 (&d)[3] = df[nb & 1];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][2], d[0], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[2], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[1], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[0], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[1], acc[kb][nb], 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[0], acc[kb][nb], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (nb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 23, 0);
+                for (int pl = 0; pl < 3; ++pl) xf[b][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[b]);
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                if (nb + 1 < 4) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) df[(nb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb + 1]);
+                }
+                const bf16x8 (&d)[3] = df[nb & 1];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][2], d[0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[2], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][1], d[0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb][0], d[0], acc[kb][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (nb + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 23, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            bf16x8 df[4][3], xf[2][3];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) df[nb][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + doff[nb]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < KBW; ++kb) {
+                if (kb + 1 < KBW) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) xf[(kb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(cur + pl * PLANE + xoff[kb + 1]);
+                }
+                const bf16x8 (&x)[3] = xf[kb & 1];
+                // the same six products in the same order per accumulator as the 8-wave form; here the four n blocks rotate
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[2], df[nb][0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], df[nb][2], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[1], df[nb][1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[1], df[nb][0], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], df[nb][1], acc[kb][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], df[nb][0], acc[kb][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kb + 1 < KBW) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 23, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -550,7 +596,7 @@ __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, c
         const int j = n0 + wn * 64 + nb * 16 + l15;
         if (j >= p.n) continue;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < KBW; ++kb) {
             const int i = k0 + wk * 64 + kb * 16 + 4 * g;
             if (vec && i + 3 < p.kvalid) {
                 *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = acc[kb][nb];

@@ -3,6 +3,9 @@
 // issue slots), which the other backward kernels of train.hip should not inherit.
 #include "gemm_tn_split.h"
 
+#ifndef DSC_TN_NCW
+#define DSC_TN_NCW 4          // consumer waves of the producer / consumer form: 4 (64 x 128 wave tiles, 512 threads: product) or 8 (64 x 64, 768 threads)
+#endif
 #ifndef DSC_TN_WS
 #define DSC_TN_WS 1          // 1: producer / consumer waves (12 waves per block, round 5); 0: the round-4 block (same-box A/B builds)
 #endif
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_split_grouped_kernel(const dsc
 }
 
 // The same launch with producer and consumer waves (gemm_tn_split.h, tn_split_block_ws): 768 threads, identical results.
-__global__ __launch_bounds__(dsc_tn_split::T_WS, 1) void gemm_tn_split_grouped_ws_kernel(const dsc_tn_group* __restrict__ groups,
+constexpr int DSC_TN_WS_THREADS = (DSC_TN_NCW + dsc_tn_split::NPW) * 64;
+__global__ __launch_bounds__(DSC_TN_WS_THREADS, 1) void gemm_tn_split_grouped_ws_kernel(const dsc_tn_group* __restrict__ groups,
                                                                                          const int2* __restrict__ block_map, const int splits,
                                                                                          float* __restrict__ workspace) {
     __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::SMEM];
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(dsc_tn_split::T_WS, 1) void gemm_tn_split_grouped_w
     // counts, 8-byte aligned bases: every activation of the denoiser); block-uniform
     const bool x2 = (((g.lda1 | g.lda2 | g.ldd) & 1) == 0) && (((g.n | g.k1 | g.k2) & 1) == 0) &&
                     ((reinterpret_cast<uintptr_t>(g.a1) | reinterpret_cast<uintptr_t>(g.a2) | reinterpret_cast<uintptr_t>(g.dy)) & 7) == 0;
-    dsc_tn_split::tn_split_block_ws(p, local % ktiles, local / ktiles, split, smem, x2);
+    dsc_tn_split::tn_split_block_ws<DSC_TN_NCW>(p, local % ktiles, local / ktiles, split, smem, x2);
 }
 
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
@@ -80,7 +84,7 @@ extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     DSC_CLEAR_STALE_ERROR();
 #if DSC_TN_WS
-    hipLaunchKernelGGL(gemm_tn_split_grouped_ws_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(dsc_tn_split::T_WS), 0, s, groups_dev,
+    hipLaunchKernelGGL(gemm_tn_split_grouped_ws_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(DSC_TN_WS_THREADS), 0, s, groups_dev,
                        reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
 #else
     hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(512), 0, s, groups_dev,
