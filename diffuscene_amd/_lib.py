@@ -154,6 +154,7 @@ SIGNATURES = {
                                           C.c_void_p]),
     "dsc_gemm_tn_grouped_split_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, c_f32p, C.c_int64,
                                                 C.c_int64, C.c_void_p]),
+    "dsc_set_tn_split_form": (C.c_int, [C.c_int32]),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,

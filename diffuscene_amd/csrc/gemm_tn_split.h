@@ -292,7 +292,6 @@ __device__ __forceinline__ void tn_split_block(const Prob& p, const int it, cons
 // the matrix pipe is busy with a consumer's MFMA.  168 VGPRs per wave (three waves per SIMD).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int NPW = 4, TP = NPW * 64;                 // producer waves / threads
-constexpr int NITP = COLS * 4 / TP;                   // 6 items per producer lane and step (dword form)
 constexpr int PAIRS = COLS / 2, NITX = PAIRS * 4 / TP;// 192 channel pairs x 4 token octets = 3 items per producer lane and step (8-byte form)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -300,7 +299,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // all four n blocks stay in registers and the x fragments stream per k block -- 36 instead of 48 fragment reads per 192 MFMAs, i.e.
 // 144 instead of 196 KB of LDS reads per step and CU; 512 threads).  Every accumulator sees the same six products in the same order.
 template <int NCW>
-__device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, const int jt, const int split, char* smem, const bool x2) {
+__device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, const int jt, const int split, char* smem) {
     static_assert(NCW == 8 || NCW == 4, "8 or 4 consumer waves");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -331,12 +330,12 @@ __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, c
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, (int)xrec, 0x00020000);
         const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000);
 #endif
-        if (x2) {
-            // 8-byte loads, TWO steps of lead.  The probes of this form (producers idle: 3830 us for the launch = the MFMA floor; staging
-            // without loads: 4459; with loads one step ahead: 6167) showed the producers waiting for their loads: a step of the consumers
-            // is 1.5 us, less than the memory latency under this kernel's own traffic.  An item is a channel PAIR x a token octet (8 loads
-            // of 8 bytes, both channels of a token at once: 24 loads per lane and step instead of 48, so that two steps in flight fit the
-            // 6-bit vmcnt), three items per lane and step, two register sets alternating by step.
+        {
+            // 8-byte loads, TWO steps of lead.  (The host guarantees 16-byte aligned operands, leading dimensions and channel counts that are
+            // multiples of 4: train_plan.HipBackend.gemm_tn_grouped.)  An item is a channel PAIR x a token octet -- 8 loads of 8 bytes, both
+            // channels of a token at once: 24 loads per lane and step, so that two steps in flight fit the 6-bit vmcnt -- three items per
+            // lane and step, two register sets alternating by step.  (Probes, profiles/r05_tn_producer_consumer.txt: producers idle 3830 us
+            // for the launch = the MFMA floor; split + plane writes 4459; + L1-hit loads 5334; + real loads 6206.)
             int ivoff[NITX], ildso[NITX], bslot[NITX];
             bool isdy[NITX];
 #pragma unroll
@@ -425,69 +424,6 @@ __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, c
             }
             return;
         }
-        // dword loads, one step of lead: operands with odd leading dimensions / channel counts or 4-byte aligned views
-        int ivoff[NITP], ildso[NITP], bslot[NITP];
-        bool isdy[NITP];
-#pragma unroll
-        for (int u = 0; u < NITP; ++u) {
-            const int t = u * TP + pt, c = t % COLS, og = t / COLS;
-            isdy[u] = __builtin_amdgcn_readfirstlane((u * TP + pw * 64) % COLS) < BN;        // wave-uniform: 384 = 6 x 64
-            const int cc = isdy[u] ? (c < dcols ? c : 0) : (c - BN < xcols ? c - BN : 0);
-            ivoff[u] = (int)((cc + 8L * og * (isdy[u] ? p.ldd : ldx)) * 4);
-            ildso[u] = c * 64 + ((og ^ ((c >> 1) & 3)) << 4);
-            bslot[u] = og * BN + c;
-        }
-        float bsum[NITP] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float ld[NITP][8];
-        auto load_item = [&](int u, int step) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            const long mb = m_begin + (long)step * BMS;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                ld[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(isdy[u] ? rdy : rx, ivoff[u],
-                                                                                           (int)((mb + e) * (isdy[u] ? p.ldd : ldx) * 4), 0));
-#else
-            (void)u; (void)step;
-#endif
-        };
-        auto store_item = [&](int u, char* stage, bool count) {
-            if (do_bias && isdy[u] && count) bsum[u] += ((ld[u][0] + ld[u][1]) + (ld[u][2] + ld[u][3])) + ((ld[u][4] + ld[u][5]) + (ld[u][6] + ld[u][7]));
-            bf16x8 a, b, c;
-            split8(ld[u], a, b, c);
-            *reinterpret_cast<bf16x8*>(stage + ildso[u]) = a;
-            *reinterpret_cast<bf16x8*>(stage + PLANE + ildso[u]) = b;
-            *reinterpret_cast<bf16x8*>(stage + 2 * PLANE + ildso[u]) = c;
-        };
-        if (steps > 0) {
-#pragma unroll
-            for (int u = 0; u < NITP; ++u) load_item(u, 0);
-#pragma unroll
-            for (int u = 0; u < NITP; ++u) store_item(u, smem, true);
-#pragma unroll
-            for (int u = 0; u < NITP; ++u) load_item(u, steps > 1 ? 1 : 0);
-        }
-        for (int s = 0; s < steps; ++s) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): my plane writes of step s are done
-            __syncthreads();                              // the consumers have left the other stage
-            char* nxt = smem + ((s + 1) & 1) * STAGE;
-            const bool more = s + 1 < steps;
-            const int s2 = s + 2 < steps ? s + 2 : steps - 1;
-#pragma unroll
-            for (int u = 0; u < NITP; ++u) {
-                __builtin_amdgcn_s_waitcnt(0x0f70 | (((NITP - 1) * 8) & 15) | ((((NITP - 1) * 8) >> 4) << 14));     // vmcnt(40): item u has landed
-                store_item(u, nxt, more);
-                load_item(u, s2);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        if (do_bias) {
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NITP; ++u)
-                if (isdy[u]) bs[bslot[u]] = bsum[u];
-            __syncthreads();
-        }
-        return;
     }
 
     // ---------------------------------------------------------------------------------------------------- consumers

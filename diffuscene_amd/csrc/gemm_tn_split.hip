@@ -2,6 +2,7 @@
 // with -fno-slp-vectorize like gemm_split.hip (scalar f32 subtractions in the operand split: packed f32 VALU beside MFMAs costs
 // issue slots), which the other backward kernels of train.hip should not inherit.
 #include "gemm_tn_split.h"
+#include <atomic>
 
 #ifndef DSC_TN_NCW
 #define DSC_TN_NCW 4          // consumer waves of the producer / consumer form: 4 (64 x 128 wave tiles, 512 threads: product) or 8 (64 x 64, 768 threads)
@@ -68,11 +69,15 @@ __global__ __launch_bounds__(DSC_TN_WS_THREADS, 1) void gemm_tn_split_grouped_ws
         p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
         p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
     }
-    // 8-byte staging loads with two steps of lead wherever the group's operands allow them (even leading dimensions and channel
-    // counts, 8-byte aligned bases: every activation of the denoiser); block-uniform
-    const bool x2 = (((g.lda1 | g.lda2 | g.ldd) & 1) == 0) && (((g.n | g.k1 | g.k2) & 1) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(g.a1) | reinterpret_cast<uintptr_t>(g.a2) | reinterpret_cast<uintptr_t>(g.dy)) & 7) == 0;
-    dsc_tn_split::tn_split_block_ws<DSC_TN_NCW>(p, local % ktiles, local / ktiles, split, smem, x2);
+    dsc_tn_split::tn_split_block_ws<DSC_TN_NCW>(p, local % ktiles, local / ktiles, split, smem);
+}
+
+// Which block body the split-bf16 weight-gradient launch runs: 1 = producer / consumer waves (round 5, default), 0 = the round-4 block
+// (every wave stages and multiplies).  Identical results; the switch exists so that a test can hold the two to each other bit for bit.
+static std::atomic<int> g_tn_form{DSC_TN_WS ? 1 : 0};
+extern "C" int dsc_set_tn_split_form(int32_t form) {
+    if (form != 0 && form != 1) return DSC_EINVAL;
+    return g_tn_form.exchange(form, std::memory_order_relaxed);
 }
 
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
@@ -83,13 +88,12 @@ extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int
     if (splits > 1 && (!workspace || workspace_floats < workspace_needed || workspace_needed < 1)) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DSC_CLEAR_STALE_ERROR();
-#if DSC_TN_WS
-    hipLaunchKernelGGL(gemm_tn_split_grouped_ws_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(DSC_TN_WS_THREADS), 0, s, groups_dev,
-                       reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
-#else
-    hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(512), 0, s, groups_dev,
-                       reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
-#endif
+    if (g_tn_form.load(std::memory_order_relaxed))
+        hipLaunchKernelGGL(gemm_tn_split_grouped_ws_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(DSC_TN_WS_THREADS), 0, s, groups_dev,
+                           reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
+    else
+        hipLaunchKernelGGL(gemm_tn_split_grouped_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(512), 0, s, groups_dev,
+                           reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
     DSC_LAUNCH_CHECK();
     if (splits > 1) return dsc_launch_reduce_grouped(groups_dev, count, total_tiles, splits, workspace, s);
     return 0;

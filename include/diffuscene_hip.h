@@ -301,6 +301,11 @@ int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count,
                                   int32_t blocks, int32_t splits, float* workspace, int64_t workspace_floats, int64_t workspace_needed,
                                   dsc_stream_t stream);
 
+/* The split-bf16 weight-gradient launch has two block bodies with IDENTICAL results: 1 = producer / consumer waves (four waves stage
+ * the operands two steps ahead, four multiply: default), 0 = the round-4 body (every wave stages and multiplies).  Returns the previous
+ * form (process-wide; launches already captured in a hipGraph keep theirs).  For tests that hold the two to each other bit for bit. */
+int dsc_set_tn_split_form(int32_t form);
+
 /* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */
 int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,
                    int64_t workspace_floats, dsc_stream_t stream);

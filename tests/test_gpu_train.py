@@ -431,6 +431,48 @@ def test_grouped_weight_gradient_gemm(scale, gemm_arith):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("splits_scale", [1, 40])
+def test_weight_gradient_block_bodies_are_bit_identical(splits_scale):
+    """The producer / consumer form of the split-bf16 weight-gradient launch (round 5: four waves stage two steps ahead, four multiply)
+    against the round-4 body (every wave stages and multiplies): same LDS image, same six products in the same order per accumulator,
+    same bias partial sums -> torch.equal on every output: strided operands, two K segments, kvalid, a ragged token tail and token slices with the slab reduction."""
+    from diffuscene_amd import _lib
+    from diffuscene_amd.train_plan import HipBackend
+    if not _lib.split_enabled():
+        pytest.skip("exact-f32 arithmetic selected")
+    M = 1290
+    shapes = [(M, 512, 512, 0, None, True), (M, 512, 512, 512, None, False), (M, 512, 32, 0, 25, True),
+              (64, 1024, 512, 0, None, True), (M, 384, 512, 0, None, False), (M, 32, 512, 0, None, True)] * splits_scale
+    outs = {}
+    for form in (0, 1):
+        prev = _lib.fn("dsc_set_tn_split_form")(form)
+        try:
+            be = HipBackend(dev())
+            items = []
+            for i, (m, n, k1, k2, kv, bias) in enumerate(shapes):
+                a, dy = rnd(m, k1, seed=100 + i).to(dev()), rnd(m, n, seed=200 + i).to(dev())
+                if i % 6 == 4:                      # a column slice of a wider buffer (leading dimension != width)
+                    wide = torch.zeros(m, n + 64, device=dev())
+                    wide[:, :n] = dy
+                    dy = wide[:, :n]
+                a2 = rnd(m, k2, seed=300 + i).to(dev()) if k2 else None
+                out = torch.full((n, kv or (k1 + k2)), float("nan"), device=dev())
+                db = torch.full((n,), float("nan"), device=dev()) if bias else None
+                items.append(dict(a=a, dy=dy, out=out, a2=a2, kvalid=kv, dbias=db))
+            step = be.gemm_tn_grouped(items)
+            be.finalize()
+            be.run([step], torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs[form] = [(it["out"].clone(), None if it["dbias"] is None else it["dbias"].clone()) for it in items]
+        finally:
+            _lib.fn("dsc_set_tn_split_form")(prev)
+    for (w0, b0), (w1, b1) in zip(outs[0], outs[1]):
+        assert bool(torch.isfinite(w1).all()) and torch.equal(w0, w1)
+        if b0 is not None:
+            assert torch.equal(b0, b1)
+
+
+@pytest.mark.gpu
 def test_condition_mlps_run_on_the_hip_gemm_and_match_torch():
     """The wrapper's condition layers (reference diffusion_scene_layout_ddpm.py:94-125, :47-51): Linear -> LeakyReLU(0.1) ->
     Linear without biases on an un-aligned input width, and the biased text projection -- forward and all gradients vs the
