@@ -37,6 +37,7 @@ pmctrain) cd /tmp && export TMPDIR=/tmp
 guard) rm -f $O/${TAG}_guard.log; timeout 300 python tools/stale_plan_repro.py arrange > $O/${TAG}_stale_plan_repro.txt 2> $O/${TAG}_stale_plan_repro.err; cat $O/${TAG}_stale_plan_repro.txt | cut -c1-700
   DSC_GUARD_LOG=$O/${TAG}_guard.log timeout 1500 python -m pytest tests/test_gpu_guard.py -q -x --durations=8 > $O/${TAG}_guard_tests.log 2>&1; tail -25 $O/${TAG}_guard_tests.log ;;
 guard20) timeout 1500 python tools/guard_run.py --mode normal --loops 20 --T 3 --train-steps 3 --out $O/${TAG}_guard_loops20.json > /dev/null 2> $O/${TAG}_guard_loops20.log; tail -4 $O/${TAG}_guard_loops20.log | cut -c1-400 ;;
+ddprehearsal) DSC_BENCH_DDP_REHEARSAL=1 timeout 600 python bench.py --no-other-configs --no-cpu-baseline --no-full-loop > $O/${TAG}_bench_ddp_rehearsal.json 2> $O/${TAG}_bench_ddp_rehearsal.err; grep -c "ok$" $O/${TAG}_bench_ddp_rehearsal.err ;;
 ddp) timeout 600 python bench.py --ddp-selftest > $O/${TAG}_bench_ddp_selftest.json 2> $O/${TAG}_bench_ddp_selftest.err; tail -1 $O/${TAG}_bench_ddp_selftest.json | cut -c1-1500 ;;
 benchf32) DSC_GEMM=f32 timeout 600 python bench.py > $O/${TAG}_bench_default_f32.json 2> $O/${TAG}_bench_default_f32.err; tail -1 $O/${TAG}_bench_default_f32.json | cut -c1-600 ;;
 *) echo "unknown step $s" ;;
