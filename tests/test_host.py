@@ -311,3 +311,48 @@ def test_flat_storage_keeps_module_semantics():
     # moving the module invalidates the storage and ensure_flat rebuilds it
     net.init_conv.weight.data = net.init_conv.weight.data.clone()
     assert not fs.valid() and ensure_flat(net) is not fs
+
+
+def test_plans_own_the_storage_their_pointers_refer_to():
+    """engine._own (round 5): a launch plan keeps a detached ALIAS of every nn.Parameter it takes a raw pointer of, so that `p.data = ...`
+    (flat.FlatStorage re-homes every parameter on the first training step) cannot free the memory under a plan or a captured hipGraph."""
+    import torch.nn as nn
+    from diffuscene_amd.engine import StalePlanError, _own
+    p = nn.Parameter(torch.arange(8, dtype=torch.float32))
+    t = torch.ones(3)
+    kept = _own((p, t, None, [p, (p, 3)], "x"))
+    assert kept[1] is t and kept[2] is None and kept[4] == "x"
+    alias = kept[0]
+    assert not isinstance(alias, nn.Parameter) and alias.data_ptr() == p.data_ptr() and not alias.requires_grad
+    assert kept[3][0].data_ptr() == p.data_ptr() and kept[3][1][0].data_ptr() == p.data_ptr() and kept[3][1][1] == 3
+    old_ptr = p.data_ptr()
+    p.data = torch.zeros(8)                                   # what FlatStorage / module.to() do
+    assert p.data_ptr() != old_ptr and alias.data_ptr() == old_ptr
+    assert torch.equal(alias, torch.arange(8, dtype=torch.float32))      # the old storage is alive and untouched
+    assert issubclass(StalePlanError, RuntimeError)
+
+
+def test_ddp_flush_schedule_names(monkeypatch):
+    """DSC_DDP_FLUSH: 'single' is the default, 'end' its alias (the name keeps its old meaning), anything unknown is refused."""
+    from diffuscene_amd.train_step import DDP_FLUSH_SCHEDULES, ddp_flush_schedule
+    monkeypatch.delenv("DSC_DDP_FLUSH", raising=False)
+    assert ddp_flush_schedule() == "single" and DDP_FLUSH_SCHEDULES == ("single", "block", "thirds")
+    for name, want in (("end", "single"), ("single", "single"), ("block", "block"), ("thirds", "thirds")):
+        monkeypatch.setenv("DSC_DDP_FLUSH", name)
+        assert ddp_flush_schedule() == want
+    monkeypatch.setenv("DSC_DDP_FLUSH", "sometimes")
+    with pytest.raises(ValueError):
+        ddp_flush_schedule()
+
+
+def test_guard_allocator_is_built_and_exports_the_pluggable_allocator_entry_points():
+    """tools/guard_alloc.cpp (test infrastructure of tests/test_gpu_guard.py) is compiled by __graft_entry__.build() and exports the two
+    functions torch.cuda.memory.CUDAPluggableAllocator binds, plus the check / statistics calls of tools/guard_run.py."""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_build", "libdsc_guard_alloc.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(so)
+    for name in ("guard_malloc", "guard_free", "guard_check", "guard_stats", "guard_mode"):
+        assert getattr(lib, name) is not None
