@@ -17,6 +17,7 @@ ACT_NONE, ACT_GELU, ACT_SILU, ACT_LEAKY01 = 0, 1, 2, 3
 SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
 MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
 TILE_GN_80_W8, TILE_GN_80_W4, TILE_160x256, TILE_160x128_W4 = 1, 2, 5, 8      # DSC_TILE_* (dsc_gemm_split_tile)
+TILE_WAVE_GN, TILE_WAVE_DENSE = 10, 11
 WS_MAX = 64
 MAX_TOKENS_PER_SCENE = 160
 
@@ -48,6 +49,7 @@ class GemmArgs(C.Structure):
         ("w_planes", C.c_void_p),
         ("actgrad_x", C.c_void_p), ("ld_actgrad", C.c_int64),
         ("ss_rows", C.c_int32),
+        ("w_planes_layout", C.c_int32),
     ]
 
 
@@ -100,6 +102,9 @@ SIGNATURES = {
     "dsc_split_bf16x3_f32": (C.c_int, [C.POINTER(SplitItem), C.c_int32, C.c_void_p]),
     "dsc_gemm_arithmetic": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
     "dsc_gemm_split_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
+    "dsc_gemm_planes_layout": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
+    "dsc_get_split_wave": (C.c_int, []),
+    "dsc_set_split_wave": (C.c_int, [C.c_int32]),
     "dsc_get_gemm_arithmetic": (C.c_int, []),
     "dsc_set_gemm_arithmetic": (C.c_int, [C.c_int32]),
     "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
@@ -220,6 +225,8 @@ def load():
         fn.argtypes = args
     if lib.dsc_get_gemm_arithmetic() < 0:
         raise ValueError("DSC_GEMM=%r: must be 'split' (default) or 'f32'" % os.environ.get("DSC_GEMM"))
+    if lib.dsc_get_split_wave() < 0:
+        raise ValueError("DSC_WAVE=%r: must be '1' / 'auto' (default) or '0'" % os.environ.get("DSC_WAVE"))
     _lib = lib
     return lib
 
@@ -228,6 +235,22 @@ def split_enabled():
     """The library's GEMM arithmetic switch (dsc_get_gemm_arithmetic): True = split-bf16 wherever a launch qualifies, False = exact-f32
     MFMA everywhere.  The ONLY place host code learns the arithmetic from -- nothing in the package parses DSC_GEMM."""
     return load().dsc_get_gemm_arithmetic() == 1
+
+
+def gemm_mode():
+    """What plans, engines and graphs bake in about the GEMM kernels: 0 = exact-f32 MFMA everywhere, 1 = split-bf16 on the block-staged
+    kernel only, 2 = split-bf16 with the wave-autonomous kernel wherever a launch qualifies (default).  They are keyed by it and
+    rebuilt on their next use after a switch."""
+    lib = load()
+    return 0 if lib.dsc_get_gemm_arithmetic() != 1 else (2 if lib.dsc_get_split_wave() == 1 else 1)
+
+
+def set_split_wave(on):
+    """Switch the wave-autonomous kernel family of the split arithmetic (dsc_set_split_wave); returns the previous setting.  Both
+    families compute bit-identical results."""
+    prev = load().dsc_get_split_wave() == 1
+    check(load().dsc_set_split_wave(1 if on else 0), "dsc_set_split_wave")
+    return prev
 
 
 def set_gemm_arithmetic(name):

@@ -23,6 +23,7 @@
 // the MFMAs of tile kt and write three bf16 planes to the other LDS stage.  The MFMA computes out^T (weights as the row operand) so
 // that a lane holds 4 consecutive channels of one token: 16-byte stores.
 #include "dsc_common.h"
+#include "gemm_split_wave.h"
 #include <atomic>
 #include <cstring>
 
@@ -70,7 +71,9 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8& p
 struct SplitBatch { dsc_split_item it[DSC_WS_MAX]; };
 
 __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch bch) {
-    const dsc_split_item it = bch.it[blockIdx.y];
+    dsc_split_item it = bch.it[blockIdx.y];
+    const bool frag = (it.transpose & DSC_SPLIT_FRAGMENT) != 0;                                    // fragment-major output (gemm_split_wave.h)
+    it.transpose &= DSC_SPLIT_TRANSPOSE;
     const int ro = it.transpose ? it.cols : it.rows, co = it.transpose ? it.rows : it.cols;       // output matrix
     const int oct = co / 8;                                                                        // 8-element items per output row
     const long items = (long)ro * oct;
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const SplitBatch bch)
         }
         bf16x8 a, b, c;
         split8(lo, hi, a, b, c);
-        uint16_t* d = it.planes + r * co + o * 8;
+        // fragment-major: [ro / 16][co / 32][lane = (k-octet & 3) * 16 + row % 16][8]
+        uint16_t* d = it.planes + (frag ? ((((r >> 4) * (co >> 5) + (o >> 2)) * 64 + (o & 3) * 16 + (r & 15)) * 8) : (r * co + o * 8));
         *reinterpret_cast<bf16x8*>(d) = a;
         *reinterpret_cast<bf16x8*>(d + plane) = b;
         *reinterpret_cast<bf16x8*>(d + 2 * plane) = c;
@@ -480,7 +484,7 @@ int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
 
 // Which split kernel takes this launch: a tile id, or -1 = none (no planes, DSC_GEMM=f32 in the environment, or a shape / alignment /
 // launch size this path does not cover: the exact-f32 MFMA kernel runs).
-enum { T_GN_32 = 0, T_GN_80_W8, T_GN_80_W4, T_GN_48, T_GN_64, T_160x256, T_256x128, T_128x128, T_160x128_W4, T_64x256 };
+enum { T_GN_32 = 0, T_GN_80_W8, T_GN_80_W4, T_GN_48, T_GN_64, T_160x256, T_256x128, T_128x128, T_160x128_W4, T_64x256, T_WAVE_GN, T_WAVE_DENSE };
 
 // The arithmetic of the GEMM entry points -- ONE source of truth for the library and its host code (engine, training plan, bench all
 // ask dsc_get_gemm_arithmetic): 1 = split-bf16 wherever a launch qualifies (default), 0 = exact-f32 MFMA everywhere.  Initial value
@@ -505,8 +509,65 @@ extern "C" int dsc_set_gemm_arithmetic(int32_t mode) {
     return 0;
 }
 
-static int select_tile(const dsc_gemm_args* a, bool gn) {
-    if (dsc_get_gemm_arithmetic() != 1 || !a->w_planes) return -1;
+// The wave-autonomous family (gemm_split_wave.h), 1 = wherever a launch qualifies, 0 = never; DSC_WAVE in the environment, strictly.
+static std::atomic<int> g_split_wave{-1000};
+
+extern "C" int dsc_get_split_wave(void) {
+    int m = g_split_wave.load(std::memory_order_relaxed);
+    if (m == -1000) {
+        const char* e = getenv("DSC_WAVE");
+        m = (!e || !e[0] || !strcmp(e, "1") || !strcmp(e, "auto")) ? 1 : !strcmp(e, "0") ? 0 : DSC_EINVAL;
+        g_split_wave.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+extern "C" int dsc_set_split_wave(int32_t mode) {
+    if (mode != 0 && mode != 1) return DSC_EINVAL;
+    g_split_wave.store(mode, std::memory_order_relaxed);
+    return 0;
+}
+
+// Does the wave-autonomous kernel take this launch?  One wave = one scene (GroupNorm form: 17..80 tokens) or one group of 80 dense rows
+// x 128 channels, one wave per SIMD: the launch must come out at a whole number of waves per SIMD, nearly (>= 75 % of the last round).
+static int select_wave(const dsc_gemm_args* a, bool gn) {
+    if (dsc_get_split_wave() != 1) return -1;
+    const int K = a->k1 + a->k2;
+    if ((a->n % 128) || (a->k1 % 64) || (a->k2 % 64) || K < 128) return -1;
+    if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return -1;
+    if (!dsc_aligned16(a->y) || (a->ldy & 3) || a->ldy < a->n) return -1;
+    if (a->bias && !dsc_aligned16(a->bias)) return -1;
+    if (a->residual && (!dsc_aligned16(a->residual) || (a->ldr & 3) || a->ldr < a->n)) return -1;
+    if (a->preact && (!dsc_aligned16(a->preact) || (a->ld_preact & 3) || a->ld_preact < a->n || a->batch != 1)) return -1;
+    if (a->actgrad_x && (gn || !dsc_aligned16(a->actgrad_x) || (a->ld_actgrad & 3) || a->ld_actgrad < a->n || a->batch != 1)) return -1;
+    if (3LL * a->batch * a->n * K * 2 >= 0x7fffffffLL) return -1;                       // 32-bit offsets into the planes
+    const int64_t ld_max = a->lda1 > a->lda2 ? a->lda1 : a->lda2;
+    if (ld_max * 4 * 96 >= 0x7fffffffLL) return -1;                                     // 32-bit byte offsets inside a wave's rows
+    long waves;
+    if (gn) {
+        const int N = a->tokens_per_scene;
+        if (N <= 16 || N > 80) return -1;
+        const bool perrow = a->ss_mode == DSC_SS_PER_TOKEN || a->ss_mode == DSC_SS_PER_SLOT;
+        if (perrow && a->ld_ss < 2 * (int64_t)a->n) return -1;
+        waves = (long)(a->m / N) * (a->n / 128);
+    } else {
+        waves = (long)((a->m + 79) / 80) * (a->n / 128) * a->batch;
+    }
+    const long rounds = (waves + 1023) / 1024;
+    if (waves < 768 || waves * 4 < rounds * 1024 * 3) return -1;
+    return gn ? T_WAVE_GN : T_WAVE_DENSE;
+}
+
+static int select_block_tile(const dsc_gemm_args* a, bool gn);
+
+// have_planes: the planes question is asked for a launch as it is (dispatch) or for a launch whose planes do not exist yet
+static int select_tile(const dsc_gemm_args* a, bool gn, bool assume_planes = false) {
+    if (dsc_get_gemm_arithmetic() != 1 || (!assume_planes && !a->w_planes)) return -1;
+    const int w = select_wave(a, gn);
+    return w >= 0 ? w : select_block_tile(a, gn);
+}
+
+static int select_block_tile(const dsc_gemm_args* a, bool gn) {
     const int K = a->k1 + a->k2;
     // grouped launches: the weights of the problems must be the row blocks of one stacked matrix (planes [3][batch n][K])
     if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return -1;
@@ -552,9 +613,14 @@ static int select_tile(const dsc_gemm_args* a, bool gn) {
 // -> 0 / error code when the split-bf16 path took the launch, DSC_SPLIT_NOT_TAKEN when the caller should run the f32-MFMA kernel
 int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
     using namespace dsc_split;
-    if (dsc_get_gemm_arithmetic() < 0) return DSC_EINVAL;                // DSC_GEMM holds an unknown value
+    if (dsc_get_gemm_arithmetic() < 0 || dsc_get_split_wave() < 0) return DSC_EINVAL;   // DSC_GEMM / DSC_WAVE hold an unknown value
     const int N = a->tokens_per_scene;
-    switch (select_tile(a, gn)) {
+    const int tile = select_tile(a, gn);
+    if (tile < 0) return DSC_SPLIT_NOT_TAKEN;
+    // the planes must have the layout the chosen kernel reads (dsc_gemm_planes_layout said which before they were made)
+    const int want = (tile == T_WAVE_GN || tile == T_WAVE_DENSE) ? DSC_PLANES_FRAGMENT : DSC_PLANES_ROWMAJOR;
+    if (a->w_planes_layout != want) return DSC_EINVAL;
+    switch (tile) {
         case T_GN_32: return launch<true, 4, 2, 2>(a, N, s);
         case T_GN_80_W8: return launch<true, 2, 4, 5>(a, N, s);
         case T_GN_80_W4: return launch<true, 2, 2, 5>(a, N, s);
@@ -565,6 +631,17 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
         case T_128x128: return launch<false, 4, 2, 2>(a, 32, s);
         case T_160x128_W4: return launch<false, 2, 2, 5>(a, 80, s);
         case T_64x256: return launch<false, 2, 4, 2>(a, 32, s);
+        case T_WAVE_DENSE: return dsc_wave::launch<false, 5>(a, a->w_planes, 80, s);
+        case T_WAVE_GN: {
+            const bool perrow = a->ss_mode == DSC_SS_PER_TOKEN || a->ss_mode == DSC_SS_PER_SLOT;
+            const int rb = (N + 15) / 16;
+            if (perrow) {
+                return rb == 5 ? dsc_wave::launch<true, 5, true>(a, a->w_planes, N, s) : rb == 4 ? dsc_wave::launch<true, 4, true>(a, a->w_planes, N, s)
+                     : rb == 3 ? dsc_wave::launch<true, 3, true>(a, a->w_planes, N, s) : dsc_wave::launch<true, 2, true>(a, a->w_planes, N, s);
+            }
+            return rb == 5 ? dsc_wave::launch<true, 5>(a, a->w_planes, N, s) : rb == 4 ? dsc_wave::launch<true, 4>(a, a->w_planes, N, s)
+                 : rb == 3 ? dsc_wave::launch<true, 3>(a, a->w_planes, N, s) : dsc_wave::launch<true, 2>(a, a->w_planes, N, s);
+        }
         default: return DSC_SPLIT_NOT_TAKEN;
     }
 }
@@ -581,6 +658,12 @@ extern "C" int dsc_gemm_split_tile(const dsc_gemm_args* a, int32_t gn) {
     return select_tile(a, gn != 0);
 }
 
+extern "C" int dsc_gemm_planes_layout(const dsc_gemm_args* a, int32_t gn) {
+    if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0) return DSC_EINVAL;
+    const int tile = select_tile(a, gn != 0, true);
+    return tile < 0 ? -1 : (tile == T_WAVE_GN || tile == T_WAVE_DENSE) ? DSC_PLANES_FRAGMENT : DSC_PLANES_ROWMAJOR;
+}
+
 extern "C" int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream) {
     using namespace dsc_split;
     if (!items || count < 1 || count > DSC_WS_MAX) return DSC_EINVAL;
@@ -589,9 +672,12 @@ extern "C" int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, 
     for (int i = 0; i < count; ++i) {
         const dsc_split_item& it = items[i];
         if (!it.w || !it.planes || it.rows <= 0 || it.cols <= 0) return DSC_EINVAL;
-        const int co = it.transpose ? it.rows : it.cols;
+        if (it.transpose & ~(DSC_SPLIT_TRANSPOSE | DSC_SPLIT_FRAGMENT)) return DSC_EINVAL;
+        const bool tr = (it.transpose & DSC_SPLIT_TRANSPOSE) != 0;
+        const int co = tr ? it.rows : it.cols, ro = tr ? it.cols : it.rows;
         if (co % 8) return DSC_EINVAL;
-        if (!dsc_aligned16(it.planes) || (!it.transpose && (!dsc_aligned16(it.w) || (it.ldw & 3)))) return DSC_EALIGN;
+        if ((it.transpose & DSC_SPLIT_FRAGMENT) && ((ro % 16) || (co % 32))) return DSC_EINVAL;
+        if (!dsc_aligned16(it.planes) || (!tr && (!dsc_aligned16(it.w) || (it.ldw & 3)))) return DSC_EALIGN;
         b.it[i] = it;
         const long n = (long)it.rows * it.cols / 8;
         if (n > max_items) max_items = n;

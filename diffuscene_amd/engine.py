@@ -103,9 +103,10 @@ class Plan:
     # ---- step emitters -------------------------------------------------------------------------
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE):
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out)
-        pl = self.eng.planes_of(w) if ops.gemm_would_use_split(g) else None       # planes only for launches that will use them
+        lay = ops.planes_layout(g)                       # planes only for launches that will use them, in the layout their kernel reads
+        pl = self.eng.planes_of(w, lay) if lay >= 0 else None
         if pl is not None:
-            g.w_planes = pl.data_ptr()
+            ops.attach_planes(g, pl, layout=lay)
         self.keep.append(_own((g, a, w, out, bias, a2, residual, pl)))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
@@ -121,9 +122,10 @@ class Plan:
         # dense [batch n][K] matrix and the problem stride one block; anything else multiplies on the f32 kernel
         whole = (stacked.dim() == 2 and stacked.is_contiguous() and w.data_ptr() == stacked.data_ptr()
                  and stacked.shape[0] == batch * w.shape[0] and stacked.shape[1] == w.shape[1] and sw == w.shape[0] * w.shape[1])
-        pl = self.eng.planes_of(stacked) if (whole and ops.gemm_would_use_split(g)) else None
+        lay = ops.planes_layout(g) if whole else -1
+        pl = self.eng.planes_of(stacked, lay) if lay >= 0 else None
         if pl is not None:
-            g.w_planes = pl.data_ptr()
+            ops.attach_planes(g, pl, layout=lay)
         self.keep.append(_own((g, a, w, out, bias, pl)))
         self.steps.append((_lib.fn("dsc_gemm_f32"), (C.byref(g),)))
         return out
@@ -132,9 +134,10 @@ class Plan:
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5,
                                tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
                                ss_index=self.t_in if ss_mode == SS_BY_INDEX else None)
-        pl = self.eng.planes_of(w) if ops.gemm_would_use_split(g, gn=True) else None
+        lay = ops.planes_layout(g, gn=True)
+        pl = self.eng.planes_of(w, lay) if lay >= 0 else None
         if pl is not None:
-            g.w_planes = pl.data_ptr()
+            ops.attach_planes(g, pl, gn=True, layout=lay)
         self.keep.append(_own((g, a, w, out, bias, a2, residual, gamma, beta, ss, pl)))
         self.steps.append((_lib.fn("dsc_gemm_gn_silu_f32"), (C.byref(g),)))
         return out
@@ -435,6 +438,7 @@ class DenoiserEngine:
         # whenever the parameters change.  With the exact-f32 arithmetic selected (_lib.split_enabled() False: DSC_GEMM=f32 or
         # set_gemm_arithmetic("f32")) no planes are made; Unet1D.engine() rebuilds the engine when the switch has moved since.
         self.split = _lib.split_enabled()
+        self.mode = _lib.gemm_mode()             # Unet1D.engine() rebuilds the engine when the kernel switches have moved since
         self._planes = {}
         ws_mods, t_blocks, c_blocks = [], [], []
         for rb, kind in net.resblocks_in_order():
@@ -488,21 +492,22 @@ class DenoiserEngine:
             self.dec_w3p = torch.zeros((Hd * self.dec_pad, D), device=device)      # output projections, zero-padded to dec_pad rows each
             self.dec_b3p = torch.zeros((Hd * self.dec_pad,), device=device)
 
-    def planes_of(self, w):
-        """bf16 planes (3, n, K) of a weight the plans multiply with (None where the split path does not apply).  The entry is
-        split on registration -- the derived weights are current whenever a plan is being built -- and again by every refresh()."""
+    def planes_of(self, w, layout=0):
+        """bf16 planes (3, n, K) of a weight the plans multiply with, in ``layout`` (ops.PLANES_ROWMAJOR / PLANES_FRAGMENT: what the
+        launch's kernel reads, ops.planes_layout); None where the split path does not apply.  The entry is split on registration --
+        the derived weights are current whenever a plan is being built -- and again by every refresh()."""
         if not self.split:
             return None
         w2 = ops.as2d(w.detach() if w.requires_grad else w)
         if w2.dim() != 2 or w2.stride(1) != 1 or not ops.planes_wanted(w2.shape[0], w2.shape[1]):
             return None
-        key = (w2.data_ptr(), tuple(w2.shape), w2.stride(0))
+        key = (w2.data_ptr(), tuple(w2.shape), w2.stride(0), layout)
         ent = self._planes.get(key)
         if ent is None:
             planes = torch.empty((3,) + tuple(w2.shape), device=self.device, dtype=torch.int16)
             with torch.no_grad():
-                ops.split_planes([(w2, planes, False)])
-            ent = self._planes[key] = (w2, planes)
+                ops.split_planes([(w2, planes, 2 * layout)])
+            ent = self._planes[key] = (w2, planes, 2 * layout)
         return ent[1]
 
     def _signature(self):
@@ -555,7 +560,7 @@ class DenoiserEngine:
                     self.dec_w3p[i * self.dec_pad:i * self.dec_pad + width].copy_(seq[4].weight.view(width, D))
                     self.dec_b3p[i * self.dec_pad:i * self.dec_pad + width].copy_(seq[4].bias)
             if self._planes:
-                ops.split_planes([(w2, planes, False) for w2, planes in self._planes.values()])
+                ops.split_planes(list(self._planes.values()))
         self.sig = sig
         self._ss_table_sig = None          # the per-timestep table is stale now (recomputed in place on demand)
 

@@ -204,8 +204,8 @@ class Unet1D(nn.Module):
 
     def engine(self, device):
         from ..engine import DenoiserEngine
-        from .._lib import split_enabled
-        if self._engine is None or self._engine_device != device or self._engine.split != split_enabled():
+        from .._lib import gemm_mode
+        if self._engine is None or self._engine_device != device or self._engine.mode != gemm_mode():
             self._engine = DenoiserEngine(self, device)
             self._engine_device = device
         return self._engine

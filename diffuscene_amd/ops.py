@@ -86,7 +86,45 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         if (w_planes.dtype != torch.int16 or w_planes.dim() != 3 or w_planes.shape[0] != 3 or w_planes.shape[1] % g.n
                 or w_planes.shape[2] != g.k1 + g.k2 or not w_planes.is_contiguous()):
             raise RuntimeError("w_planes must be a contiguous int16 tensor of shape (3, %d, %d)" % (g.n, g.k1 + g.k2))
-        g.w_planes = w_planes.data_ptr()
+        attach_planes(g, w_planes, gn=gamma is not None)
+    return g
+
+
+PLANES_ROWMAJOR, PLANES_FRAGMENT = 0, 1
+
+
+def planes_layout(g, gn=False):
+    """Which layout of the weight's bf16 planes this launch wants (dsc_gemm_planes_layout): PLANES_ROWMAJOR (the block-staged split
+    kernel), PLANES_FRAGMENT (the wave-autonomous kernel reads MFMA fragments straight from memory), or -1: the launch stays on the
+    exact-f32 kernel whatever it is given.  Asked BEFORE planes are made."""
+    r = _lib.fn("dsc_gemm_planes_layout")(C.byref(g), 1 if gn else 0)
+    if r < -1:
+        _lib.check(r, "dsc_gemm_planes_layout")
+    return r
+
+
+def fragment_major(planes):
+    """Row-major planes (3, n, K) -> the same values fragment-major, [3][n/16][K/32][lane = (k-octet & 3) * 16 + row % 16][8] (kept in a
+    tensor of the same shape)."""
+    _, n, k = planes.shape
+    return planes.view(3, n // 16, 16, k // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(3, n, k)
+
+
+def attach_planes(g, planes, gn=False, layout=None):
+    """Hand ``planes`` to the launch.  ``layout`` says how they are laid out (what split_planes(..., fragment=) made); None = row-major
+    planes from an ad-hoc caller (tests, tools): where the library wants the other layout for this launch a converted copy is made
+    once and kept on the tensor -- plans ask planes_layout() first and split straight into the layout they need."""
+    want = planes_layout(g, gn)
+    if layout is None:
+        layout = getattr(planes, "_dsc_layout", PLANES_ROWMAJOR)
+        if want == PLANES_FRAGMENT and layout == PLANES_ROWMAJOR:
+            cached = getattr(planes, "_dsc_fragment", None)
+            if cached is None or cached[0] != planes._version:
+                cached = planes._dsc_fragment = (planes._version, fragment_major(planes))
+            planes, layout = cached[1], PLANES_FRAGMENT
+            g._planes_keep = planes                 # the struct holds a raw pointer: keep the converted copy with it
+    g.w_planes = planes.data_ptr()
+    g.w_planes_layout = layout
     return g
 
 
@@ -100,6 +138,8 @@ def split_planes(items, stream=None):
     tensor (3, rows, cols) -- or (3, cols, rows) when ``transpose`` -- or None (allocated).  Returns the planes tensors."""
     out, batch = [], []
     for w, planes, tr in items:
+        tr = int(tr)                       # bit 0: planes of w^T; bit 1 (2): fragment-major output (PLANES_FRAGMENT)
+        frag, tr = tr & 2, tr & 1
         w2 = as2d(_dev(w, "w"))
         ptr, ldw = _mat(w2, "w")
         r, c = w2.shape
@@ -108,8 +148,9 @@ def split_planes(items, stream=None):
             planes = torch.empty(shape, device=w2.device, dtype=torch.int16)
         elif tuple(planes.shape) != shape or planes.dtype != torch.int16 or not planes.is_contiguous():
             raise RuntimeError("split_planes: planes must be contiguous int16 %s" % (shape,))
+        planes._dsc_layout = PLANES_FRAGMENT if frag else PLANES_ROWMAJOR
         out.append(planes)
-        batch.append((ptr, ldw, r, c, planes.data_ptr(), 1 if tr else 0, w2, planes))
+        batch.append((ptr, ldw, r, c, planes.data_ptr(), (1 if tr else 0) | frag, w2, planes))
     for i in range(0, len(batch), _lib.WS_MAX):
         part = batch[i:i + _lib.WS_MAX]
         arr = (SplitItem * len(part))()
@@ -129,12 +170,7 @@ def gemm_would_use_split(g, gn=False):
     """The same question BEFORE any planes exist: would this launch take the split path if the weight's planes were supplied?
     (Callers skip the plane copy -- 6 bytes per weight and a split launch per weight update -- for launches that stay on the
     exact-f32 kernel anyway: too few blocks, unsupported shape, DSC_GEMM=f32.)"""
-    saved = g.w_planes
-    g.w_planes = g.w                      # any non-null 16-byte aligned address: the decision does not read it
-    try:
-        return gemm_uses_split(g, gn)
-    finally:
-        g.w_planes = saved
+    return planes_layout(g, gn) >= 0
 
 
 def run_gemm(g, gn=False, stream=None):

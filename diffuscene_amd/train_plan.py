@@ -137,12 +137,13 @@ class HipBackend:
         self.transposed_of = {}                  # data_ptr of a dense [K][n] buffer -> source weight [n][K]
         self.f32_reads = set()                   # storage pointers of weight operands read WITHOUT planes
 
-    def planes_of(self, w, rows):
-        """bf16 planes of weight operand ``w`` ([n][K], rows contiguous) for a product with ``rows`` activation rows, or None."""
+    def planes_of(self, w, rows, layout=0):
+        """bf16 planes of weight operand ``w`` ([n][K], rows contiguous) for a product with ``rows`` activation rows, in ``layout``
+        (ops.planes_layout of the launch: row-major for the block-staged split kernel, fragment-major for the wave-autonomous one), or None."""
         from . import ops
         if not self.split or rows < 256 or w.dim() != 2 or w.stride(1) != 1 or not ops.planes_wanted(w.shape[0], w.shape[1]):
             return None
-        key = (w.data_ptr(), tuple(w.shape), w.stride(0))
+        key = (w.data_ptr(), tuple(w.shape), w.stride(0), layout)
         ent = self._planes.get(key)
         if ent is None:
             planes = torch.empty((3,) + tuple(w.shape), device=self.device, dtype=torch.int16)
@@ -152,7 +153,7 @@ class HipBackend:
                 src = None                       # a column slice / padded view of the transposed buffer: split the buffer itself
             if src is None:
                 self.f32_reads.add(w.untyped_storage().data_ptr())       # the split launch reads this buffer as f32
-            ent = self._planes[key] = (w, planes, src)
+            ent = self._planes[key] = (w, planes, src, 2 * layout)
             self._planes_new.append(ent)
         return ent[1]
 
@@ -165,15 +166,15 @@ class HipBackend:
         for i in range(0, len(ents), self.lib.WS_MAX):
             part = ents[i:i + self.lib.WS_MAX]
             arr = (self.lib.SplitItem * len(part))()
-            for j, (w, planes, src) in enumerate(part):
+            for j, (w, planes, src, frag) in enumerate(part):      # frag: 2 = fragment-major output (DSC_SPLIT_FRAGMENT)
                 if src is not None:              # planes of w = src^T, read from the source: the f32 copy w is never needed for this
                     ptr, ldw = ops._mat(src, "w")
                     arr[j].w, arr[j].ldw, arr[j].rows, arr[j].cols, arr[j].planes, arr[j].transpose = (
-                        ptr, ldw, src.shape[0], src.shape[1], planes.data_ptr(), 1)
+                        ptr, ldw, src.shape[0], src.shape[1], planes.data_ptr(), 1 | frag)
                     continue
                 ptr, ldw = ops._mat(w, "w")
                 arr[j].w, arr[j].ldw, arr[j].rows, arr[j].cols, arr[j].planes, arr[j].transpose = (
-                    ptr, ldw, w.shape[0], w.shape[1], planes.data_ptr(), 0)
+                    ptr, ldw, w.shape[0], w.shape[1], planes.data_ptr(), frag)
             steps.append(self._call("dsc_split_bf16x3_f32", arr, len(part), keep=(arr, part)))
         return steps
 
@@ -213,17 +214,19 @@ class HipBackend:
             return False
         g = ops.make_gemm_args(a, w, out, bias, a2, act_out=ACT_GELU if (preact is not None or actgrad_x is not None) else ACT_NONE,
                                preact=preact, actgrad_x=actgrad_x)
-        return ops.gemm_would_use_split(g) and self.planes_of(w, a.shape[0]) is not None
+        lay = ops.planes_layout(g)
+        return lay >= 0 and self.planes_of(w, a.shape[0], lay) is not None
 
     def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_out=ACT_NONE, preact=None, actgrad_x=None):
         from . import ops
         m, K = a.shape
         if preact is not None or actgrad_x is not None:
             g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out, preact=preact, actgrad_x=actgrad_x)
-            pl = self.planes_of(w, m)
-            if pl is None or not ops.gemm_would_use_split(g):
+            lay = ops.planes_layout(g)
+            pl = self.planes_of(w, m, lay) if lay >= 0 else None
+            if pl is None:
                 raise RuntimeError("HipBackend.gemm: an activation epilogue was planned for a launch the split kernel does not take")
-            g.w_planes = pl.data_ptr()
+            ops.attach_planes(g, pl, layout=lay)
             return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl, preact, actgrad_x))
         # short, deep products (time / context MLPs: m = B or N rows, K >= 1024): split K over the batch dimension
         tiles = ((m + 63) // 64) * ((out.shape[1] + 63) // 64)        # output tiles: fewer than CUs -> parallelise K instead
@@ -237,9 +240,10 @@ class HipBackend:
                 self.f32_reads.add(w.untyped_storage().data_ptr())
                 return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
-        pl = self.planes_of(w, m) if ops.gemm_would_use_split(g) else None          # planes only for launches that will use them
+        lay = ops.planes_layout(g)                      # planes only for launches that will use them, in the layout their kernel reads
+        pl = self.planes_of(w, m, lay) if lay >= 0 else None
         if pl is not None:
-            g.w_planes = pl.data_ptr()
+            ops.attach_planes(g, pl, layout=lay)
         else:
             self.f32_reads.add(w.untyped_storage().data_ptr())
         return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl))
@@ -266,9 +270,10 @@ class HipBackend:
         from . import ops
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5, tokens_per_scene=n_tok,
                                scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE, preact=preact)
-        pl = self.planes_of(w, a.shape[0]) if ops.gemm_would_use_split(g, gn=True) else None
+        lay = ops.planes_layout(g, gn=True)
+        pl = self.planes_of(w, a.shape[0], lay) if lay >= 0 else None
         if pl is not None:
-            g.w_planes = pl.data_ptr()
+            ops.attach_planes(g, pl, gn=True, layout=lay)
         else:
             self.f32_reads.add(w.untyped_storage().data_ptr())
         return self._call("dsc_gemm_gn_silu_f32", C.byref(g), keep=(g, a, w, out, bias, gamma, beta, a2, ss, residual, preact, pl))

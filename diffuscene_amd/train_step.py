@@ -110,8 +110,8 @@ class PlanRunner:
         flush = ddp_flush_schedule()
         per_block = distributed and flush == "block"
         thirds = distributed and flush == "thirds"
-        from ._lib import split_enabled
-        arith = split_enabled() if PlanRunner.backend_factory is None else None      # plans bake the arithmetic in (planes, TN form)
+        from ._lib import gemm_mode
+        arith = gemm_mode() if PlanRunner.backend_factory is None else None      # plans bake the arithmetic and kernel family in (planes, TN form)
         key = (B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param is not None, ws, distributed, per_block, thirds, arith)
         ent = self.plans.pop(key, None)
         if ent is None:

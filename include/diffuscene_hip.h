@@ -96,7 +96,15 @@ typedef struct dsc_gemm_args {
     /* DSC_SS_BY_INDEX: rows of the scale_shift table (>= 1).  Every gathered index is clamped into [0, ss_rows) on the device, so a
      * timestep vector left out of range (e.g. -1 after the last step of a captured reverse loop) cannot read outside the table. */
     int32_t ss_rows;
+    /* Layout of w_planes (round 6): DSC_PLANES_ROWMAJOR = [3][n][K] (the block-staged split kernel stages them through LDS);
+     * DSC_PLANES_FRAGMENT = [3][n/16][K/32][64 lanes][8]: one 1 KiB piece per (16-channel block, K tile, plane) in MFMA lane order, read
+     * straight into registers by the wave-autonomous kernel (csrc/gemm_split_wave.h).  Which one a launch wants is the library's
+     * decision -- ask dsc_gemm_planes_layout() BEFORE making the planes; a launch whose planes have the other layout fails with
+     * DSC_EINVAL (it is never computed on the wrong bytes, never silently sent to another kernel). */
+    int32_t w_planes_layout;
 } dsc_gemm_args;
+#define DSC_PLANES_ROWMAJOR 0
+#define DSC_PLANES_FRAGMENT 1
 
 int dsc_gemm_f32(const dsc_gemm_args* args, dsc_stream_t stream);
 
@@ -120,7 +128,19 @@ int dsc_gemm_arithmetic(const dsc_gemm_args* args, int32_t gn);
 #define DSC_TILE_128x128     7
 #define DSC_TILE_160x128_W4  8   /* dense rows, 4 waves */
 #define DSC_TILE_64x256      9
+#define DSC_TILE_WAVE_GN     10  /* wave-autonomous kernel: one scene of 17..80 tokens x 128 channels per wave, 4 waves per block */
+#define DSC_TILE_WAVE_DENSE  11  /* the same on dense rows (groups of 80) */
 int dsc_gemm_split_tile(const dsc_gemm_args* args, int32_t gn);
+
+/* The planes layout the launch wants: DSC_PLANES_ROWMAJOR / DSC_PLANES_FRAGMENT, or -1 when it stays on the exact-f32 kernel whatever
+ * planes it is given (w_planes / w_planes_layout of `args` are not read). */
+int dsc_gemm_planes_layout(const dsc_gemm_args* args, int32_t gn);
+
+/* The wave-autonomous kernel family of the split arithmetic: 1 = used wherever a launch qualifies (default), 0 = never (every split
+ * launch on the block-staged kernel: the round-3..5 behaviour).  Initial value from DSC_WAVE ("", "1", "auto" -> 1; "0" -> 0; anything
+ * else -> DSC_EINVAL from get and from every GEMM launch).  Both families compute bit-identical results (tests/test_gpu_split.py). */
+int dsc_get_split_wave(void);
+int dsc_set_split_wave(int32_t mode);
 
 /* The arithmetic switch of dsc_gemm_f32 / dsc_gemm_gn_silu_f32 / the grouped weight-gradient launch chosen by the host code -- the ONE
  * source of truth (the Python engine, the training plan and bench.py ask this function, nothing else parses the environment):
@@ -131,6 +151,10 @@ int dsc_gemm_split_tile(const dsc_gemm_args* args, int32_t gn);
 int dsc_get_gemm_arithmetic(void);
 int dsc_set_gemm_arithmetic(int32_t mode);
 
+/* transpose: bit 0 = planes of w^T; bit 1 (DSC_SPLIT_FRAGMENT) = fragment-major output (DSC_PLANES_FRAGMENT; output rows % 16 == 0,
+ * output columns % 32 == 0) */
+#define DSC_SPLIT_TRANSPOSE 1
+#define DSC_SPLIT_FRAGMENT  2
 typedef struct dsc_split_item { const float* w; int64_t ldw; int32_t rows, cols; uint16_t* planes; int32_t transpose; } dsc_split_item;
 int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream);
 

@@ -183,10 +183,17 @@ def test_four_wave_and_eight_wave_tiles_are_bit_identical(mode):
             y = ops.gemm_gn_silu(a[sl], w, b, gamma, beta, N, a2=a2[sl] if k2 else None, residual=res[sl], w_planes=pl, **kw)
             return tile, y
 
-        t8, y8 = gn(M, B)
-        t4, y4 = gn(h, B // 2)
-        assert (t8, t4) == (_lib.TILE_GN_80_W8, _lib.TILE_GN_80_W4), (t8, t4)
+        prev = _lib.set_split_wave(False)
+        try:
+            t8, y8 = gn(M, B)
+            t4, y4 = gn(h, B // 2)
+            _lib.set_split_wave(True)                     # round 6: the wave-autonomous kernel takes the B = 256 launch by default
+            tw, yw = gn(M, B)
+        finally:
+            _lib.set_split_wave(prev)
+        assert (t8, t4, tw) == (_lib.TILE_GN_80_W8, _lib.TILE_GN_80_W4, _lib.TILE_WAVE_GN), (t8, t4, tw)
         assert torch.equal(y8[:h], y4), "GroupNorm GEMM: the 4-wave and the 8-wave tile differ"
+        assert torch.equal(y8, yw), "GroupNorm GEMM: the wave-autonomous kernel and the 8-wave tile differ"
         if mode == 0:
             def plain(rows):
                 sl = slice(0, rows)
@@ -195,10 +202,17 @@ def test_four_wave_and_eight_wave_tiles_are_bit_identical(mode):
                 tile = _lib.fn("dsc_gemm_split_tile")(g, 0)
                 ops.run_gemm(g)
                 return tile, out
-            p8, z8 = plain(M)
-            p4, z4 = plain(h)
-            assert (p8, p4) == (_lib.TILE_160x256, _lib.TILE_160x128_W4), (p8, p4)
+            prev = _lib.set_split_wave(False)
+            try:
+                p8, z8 = plain(M)
+                p4, z4 = plain(h)
+                _lib.set_split_wave(True)
+                pw, zw = plain(M)
+            finally:
+                _lib.set_split_wave(prev)
+            assert (p8, p4, pw) == (_lib.TILE_160x256, _lib.TILE_160x128_W4, _lib.TILE_WAVE_DENSE), (p8, p4, pw)
             assert torch.equal(z8[:h], z4), "dense GEMM: the 4-wave and the 8-wave tile differ"
+            assert torch.equal(z8, zw), "dense GEMM: the wave-autonomous kernel and the 8-wave tile differ"
 
 
 def test_split_path_falls_back_where_it_does_not_apply():
