@@ -529,11 +529,13 @@ extern "C" int dsc_set_split_wave(int32_t mode) {
 }
 
 // Does the wave-autonomous kernel take this launch?  One wave = one scene (GroupNorm form: 17..80 tokens) or one group of 80 dense rows
-// x 128 channels, one wave per SIMD: the launch must come out at a whole number of waves per SIMD, nearly (>= 75 % of the last round).
+// x 128 channels, one wave per SIMD: the launch must come out at a whole number of waves per SIMD, nearly (>= 80 % of the chip in every
+// round; measured, profiles/r06_plan_profile_sample_wave{0,1}.txt: n = 384 at M = 20480 = 768 waves, three per CU, 45.8 vs 42.7 us on the
+// block-staged 256 x 128 tile), and K >= 256 (a four-tile K loop does not pay for the longer prologue: 29.7 vs 28.2 us).
 static int select_wave(const dsc_gemm_args* a, bool gn) {
     if (dsc_get_split_wave() != 1) return -1;
     const int K = a->k1 + a->k2;
-    if ((a->n % 128) || (a->k1 % 64) || (a->k2 % 64) || K < 128) return -1;
+    if ((a->n % 128) || (a->k1 % 64) || (a->k2 % 64) || K < 256) return -1;
     if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return -1;
     if (!dsc_aligned16(a->y) || (a->ldy & 3) || a->ldy < a->n) return -1;
     if (a->bias && !dsc_aligned16(a->bias)) return -1;
@@ -554,7 +556,7 @@ static int select_wave(const dsc_gemm_args* a, bool gn) {
         waves = (long)((a->m + 79) / 80) * (a->n / 128) * a->batch;
     }
     const long rounds = (waves + 1023) / 1024;
-    if (waves < 768 || waves * 4 < rounds * 1024 * 3) return -1;
+    if (waves * 5 < rounds * 1024 * 4) return -1;
     return gn ? T_WAVE_GN : T_WAVE_DENSE;
 }
 

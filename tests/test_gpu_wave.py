@@ -48,15 +48,15 @@ def test_fragment_major_planes_hold_the_same_values():
     assert tuple(fragt.shape) == (3, 160, 384)
 
 
-@pytest.mark.parametrize("N,scenes", [(80, 256), (70, 256), (48, 256), (33, 256), (21, 256), (80, 512), (80, 200)])
+@pytest.mark.parametrize("N,scenes", [(80, 256), (70, 256), (48, 256), (33, 256), (21, 256), (80, 512), (80, 210)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_groupnorm_forms_agree_bit_for_bit(N, scenes, mode):
     """Block.forward as one launch: no / per-token / per-scene / per-slot / per-timestep (scale, shift); residual; saved pre-activation;
-    one and two K segments; whole and ragged last MFMA block (N = 70, 33, 21); 1, 2 and 0.78 rounds of waves."""
+    one and two K segments; whole and ragged last MFMA block (N = 70, 33, 21); 1, 2 and 0.82 rounds of waves."""
     from diffuscene_amd import _lib, ops
     n, d = 512, dev()
     M = scenes * N
-    for k1, k2, res, pre in ((512, 0, False, False), (512, 512, True, True), (128, 0, True, False)):
+    for k1, k2, res, pre in ((512, 0, False, False), (512, 512, True, True), (256, 0, True, False)):
         a, a2 = rnd(M, k1, seed=N + 1), (rnd(M, k2, seed=N + 2) if k2 else None)
         w, b = rnd(n, k1 + k2, seed=3, scale=0.06), rnd(n, seed=4)
         gamma, beta = rnd(n, seed=5) + 1.5, rnd(n, seed=6)
@@ -76,7 +76,7 @@ def test_groupnorm_forms_agree_bit_for_bit(N, scenes, mode):
             return tile, y, z
         (tb, yb, zb), (tw, yw, zw) = both_families(run)
         waves = scenes * n // 128
-        if waves >= 768 and waves * 4 >= -(-waves // 1024) * 1024 * 3:
+        if waves * 5 >= -(-waves // 1024) * 1024 * 4:
             assert tw == _lib.TILE_WAVE_GN and tb != tw, (tb, tw)
         assert torch.isfinite(yw).all()
         assert torch.equal(yb, yw), "GroupNorm GEMM N=%d mode=%d K=%d+%d: wave kernel != block kernel" % (N, mode, k1, k2)

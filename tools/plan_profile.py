@@ -52,7 +52,8 @@ for idx, (f, a) in enumerate(steps):
     if f is gemm_f or f is gn_f:
         g = a[0]._obj
         fl = 2.0 * g.m * g.n * (g.k1 + g.k2) * max(g.batch, 1)
-        desc = "%s%s m=%d n=%d k=%d+%d b=%d act=%d res=%d%s%s" % ("gn_gemm" if f is gn_f else "gemm", "*" if g.w_planes else "", g.m, g.n,
+        tile = _lib.fn("dsc_gemm_split_tile")(g, 1 if f is gn_f else 0)
+        desc = "%s%s m=%d n=%d k=%d+%d b=%d act=%d res=%d%s%s" % ("gn_gemm" if f is gn_f else "gemm", ("*t%d" % tile) if g.w_planes else "", g.m, g.n,
                                                                 g.k1, g.k2, g.batch, g.act_out, 1 if g.residual else 0,
                                                                 " +preact" if (g.preact and f is gemm_f) else "",
                                                                 " *act'" if g.actgrad_x else "")
