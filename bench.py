@@ -84,7 +84,7 @@ def build_model(spec, device, time_num=1000):
     import torch
     from diffuscene_amd.flat import ensure_flat
     from diffuscene_amd.networks.diffusion_scene_layout_ddpm import DiffusionSceneLayout_DDPM
-    from oracle import weights as W
+    from diffuscene_amd import workloads as W          # (the product's benchmark never needs oracle/: only the cpu_baseline leg does)
     stats = os.path.join(tempfile.mkdtemp(), "dataset_stats.txt")
     with open(stats, "w") as f:
         json.dump(W.DATASET_STATS, f)
@@ -119,7 +119,7 @@ def build_model(spec, device, time_num=1000):
 
 def synth_batch(spec, device, seed):
     import torch
-    from oracle import weights as W
+    from diffuscene_amd import workloads as W
     B, N, nc = spec["batch"], spec["objects"], spec["class_dim"]
     x = W.synth_scene_batch(B, N, nc, 32, seed=seed).to(device)
     sample = {"translations": x[:, :, 0:3].contiguous(), "sizes": x[:, :, 3:6].contiguous(),
@@ -578,12 +578,34 @@ def cpu_baseline(spec, mode, sweep=False):
         per_step.sort()
         times[f.__name__] = (per_step[len(per_step) // 2], len(per_step))          # median of the timed full-batch steps
         log("cpu_baseline: %s, %d threads: median %.3f s over %d full-batch steps" % (f.__name__, best[0], times[f.__name__][0], len(per_step)))
+    # SURVEY 8d prescribes set_num_threads(os.cpu_count()): that figure too (one warm-up + one / two timed full-batch steps per kind; on
+    # the 128-thread hosts of this pool it is the SLOWER setting -- oversubscribed memory-bound ops -- which is why the headline value
+    # above uses the measured optimum)
+    all_cores = None
+    if not sweep and os.environ.get("DSC_CPU_BASELINE_ALL_CORES", "1") != "0" and ncpu > fixed:
+        torch.set_num_threads(ncpu)
+        ac = {}
+        for f in legs:
+            f()
+            d = []
+            for _ in range(2 if f is sample_step else 1):
+                t1 = time.perf_counter()
+                f()
+                d.append(time.perf_counter() - t1)
+            ac[f.__name__] = min(d)
+            log("cpu_baseline: %s, ALL %d threads: %.3f s per full-batch step" % (f.__name__, ncpu, ac[f.__name__]))
+        all_cores = {"threads": ncpu, "value": round(len(ac) / sum(ac.values()), 4), "unit": "steps/s"}
+        for k, v in ac.items():
+            all_cores[k.replace("_step", "") + "_steps_per_s"] = round(1.0 / v, 4)
+        torch.set_num_threads(fixed)
     threads = max(threads_of.values())
     per = sum(v[0] for v in times.values()) / len(times)            # 'both': mean of the two step kinds (1:1 mix)
     model, phys = _cpu_info()
     out = {"value": round(1.0 / per, 4), "unit": "steps/s", "cores": threads, "kind": "port",
-           "why_port": "the reference tree (/root/reference) does not exist on the GPU box, so its modules cannot be timed here; the "
-                       "port is the same PyTorch-CPU ops in the same order (oracle/ref_torch.py), pinned to the real modules as below",
+           "why_port": "the reference is Python and, by the rules of this build, cannot travel to the GPU box in any form (source, bytecode "
+                       "or otherwise; /root/reference does not exist there), so its own modules cannot be timed here; the port is the same "
+                       "PyTorch-CPU ops in the same order (oracle/ref_torch.py), pinned to the real modules as below",
+           "all_cores": all_cores,
            "statistic": "median of >= 3 (sampling) / >= 2 (training) full-batch steps after a warm-up step, at a fixed thread count (the "
                         "full-batch optimum is flat from 8 to 32 threads for both step kinds: profiles/r05_cpu_baseline_sweep.txt)",
            "threads_per_step_kind": {k.replace("_step", ""): v for k, v in threads_of.items()},
@@ -634,6 +656,68 @@ def side_line(name, device, arith=None, steps=6, warm=3):
         torch.cuda.empty_cache()
         if prev is not None:
             _lib.set_gemm_arithmetic(prev)
+
+
+def public_api_line(device):
+    """What a user of the drop-in gets from the PUBLIC sampling entry points, wall time including everything the method does (condition
+    build, x_T draw, 1000 reverse steps, post-filter, copy to the host) -- round-5 review items 4 / 5:
+      generate_b1_n12 / _n21   network.generate_layout(batch_size=1), the call of scripts/generate_diffusion.py:314-323 (one scene per call),
+                               with the default environment (captured hipGraph loop since round 6) and with DSC_GRAPH=0 (eager loop:
+                               ~110 ctypes launches per step from Python); first call (capture) and steady state apart
+      generate_batched_b256    network.generate_layout_batched(batch_size=256) at the metric shape (N = 80)"""
+    import torch
+    out = {}
+
+    def wall(fn, reps):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    for name, N in (("generate_b1_n12", 12), ("generate_b1_n21", 21)):
+        spec = dict(CONFIGS["bedroom21"], batch=1, objects=N)
+        model, cfg = build_model(spec, device)
+        model.eval()
+        room = torch.zeros(1, 1, 64, 64, device=device)
+        call = lambda: model.generate_layout(room_mask=room, num_points=N, point_dim=cfg["point_dim"], batch_size=1, text=None,  # noqa: E731
+                                             device="cpu", clip_denoised=True)
+        row = {"workload": "uncond bedrooms, generate_layout(batch_size=1), N=%d, T=1000" % N}
+        with contextlib.redirect_stdout(io.StringIO()):
+            os.environ.pop("DSC_GRAPH", None)
+            first = wall(call, 1)[0]
+            ts = sorted(wall(call, 3))
+            row["default_env"] = {"loop": "captured hipGraph step (default)", "first_call_s": round(first, 3), "seconds_per_scene": round(ts[1], 4),
+                                  "denoiser_steps_per_s": round(1000.0 / ts[1], 1)}
+            os.environ["DSC_GRAPH"] = "0"
+            wall(call, 1)
+            te = sorted(wall(call, 2))
+            os.environ.pop("DSC_GRAPH", None)
+            row["DSC_GRAPH=0"] = {"loop": "eager Python loop", "seconds_per_scene": round(te[0], 4), "denoiser_steps_per_s": round(1000.0 / te[0], 1)}
+        row["graph_over_eager"] = round(te[0] / ts[1], 2)
+        out[name] = row
+        log("public_api: %s default %.3f s / scene (first call %.2f s), eager %.3f s" % (name, ts[1], first, te[0]))
+        del model
+        torch.cuda.empty_cache()
+    spec = dict(CONFIGS["living80"])
+    model, cfg = build_model(spec, device)
+    model.eval()
+    B, N = spec["batch"], spec["objects"]
+    room = torch.zeros(B, 1, 64, 64, device=device)
+    call = lambda: model.generate_layout_batched(room_mask=room, num_points=N, point_dim=cfg["point_dim"], batch_size=B, text=None,  # noqa: E731
+                                                 clip_denoised=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        first = wall(call, 1)[0]
+        ts = sorted(wall(call, 2))
+    out["generate_batched_b256"] = {"workload": "uncond living rooms, generate_layout_batched(batch_size=%d), N=%d, T=1000: condition build, x_T, "
+                                                "1000 replayed steps, per-scene post-filter on the device, one copy to the host" % (B, N),
+                                    "first_call_s": round(first, 3), "seconds": round(ts[0], 3), "scenes_per_s": round(B / ts[0], 1),
+                                    "denoiser_steps_per_s": round(1000.0 / ts[0], 1)}
+    log("public_api: generate_layout_batched B=%d %.3f s" % (B, ts[0]))
+    return out
 
 
 def side_line_child(what, timeout=600):
@@ -809,7 +893,7 @@ def main():
         if ws != 1:
             raise SystemExit("bench.py: --side-line is a single-GPU run")
         name, _, arith = args.side_line.partition(":")
-        print(json.dumps(side_line(name, device, arith=arith or None)), flush=True)
+        print(json.dumps(public_api_line(device) if name == "public_api" else side_line(name, device, arith=arith or None)), flush=True)
         return
 
     spec = dict(CONFIGS[args.config])
@@ -981,6 +1065,8 @@ def main():
             if _lib.split_enabled():
                 out["exact_f32"] = side_line_child("living80:f32")
                 log("exact_f32 done")
+            out["public_api"] = side_line_child("public_api")
+            log("public_api done")
         if rehearsal:
             out["ddp_rehearsal"] = "world-1 RCCL group, reducer forced on: the multi-GPU code path of this script on ONE GPU (not a scaling number)"
         print(json.dumps(out), flush=True)

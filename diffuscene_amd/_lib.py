@@ -272,6 +272,15 @@ def device_error_count(reset=False):
     return int(n)
 
 
+def check_indices(where):
+    """DSC_CHECK_INDICES=1 (debugging): raise if a DDPM kernel had to clamp an out-of-range device timestep since the last check -- the
+    reference's gather would have raised an index error there; the kernels clamp (memory-safe) and count.  Synchronises the device."""
+    if os.environ.get("DSC_CHECK_INDICES", "0") == "1":
+        n = device_error_count(reset=True)
+        if n:
+            raise IndexError("%s: %d out-of-range device timestep(s) were clamped into the schedule tables" % (where, n))
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))

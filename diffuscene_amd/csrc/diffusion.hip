@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
                                                       const float* __restrict__ sb, float* __restrict__ xt,
                                                       float* __restrict__ vout, int64_t inner, int T) {
     const int b = blockIdx.y;
-    const int64_t tv = dsc_checked_index(t[b], T);
+    const int64_t tv = dsc_checked_index(t[b], T, blockIdx.x == 0 && threadIdx.x == 0);      // one count per out-of-range scene
     const float a = sa[tv], s = sb[tv];
     const int64_t base = (int64_t)b * inner;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (int64_t)gridDim.x * blockDim.x) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void p_sample_kernel(const float* xt, const fl
                                                       const float* __restrict__ sigma, float* out,   // out may alias xt (in-place step)
                                                       float* __restrict__ x0_out, int mean_type, int clip, int64_t inner, int T) {
     const int b = blockIdx.y;
-    const int64_t tv = dsc_checked_index(t[b], T);
+    const int64_t tv = dsc_checked_index(t[b], T, blockIdx.x == 0 && threadIdx.x == 0);      // one count per out-of-range scene
     const float A = (mean_type == DSC_MEAN_X0) ? 0.f : ca[tv];
     const float Bc = (mean_type == DSC_MEAN_X0) ? 0.f : cb[tv];
     const float k1 = c1[tv], k2 = c2[tv];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void complete_overwrite_kernel(float* __restri
                                                                 const int64_t* __restrict__ t, const float* __restrict__ sa,
                                                                 const float* __restrict__ sb, int n, int p, int c, int T) {
     const int b = blockIdx.y;
-    const int64_t tv = dsc_checked_index(t[b], T);
+    const int64_t tv = dsc_checked_index(t[b], T, blockIdx.x == 0 && threadIdx.x == 0);      // one count per out-of-range scene
     const float a = sa[tv], s = sb[tv];
     const int64_t cnt = (int64_t)p * c;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {

@@ -125,10 +125,12 @@ int dsc_launch_reduce_grouped(const dsc_tn_group* groups_dev, int count, int tot
 // DSC_BAD_INDEX_COUNTER before including this header.
 #ifdef DSC_BAD_INDEX_COUNTER
 static __device__ unsigned int dsc_bad_index_count = 0;
-__device__ __forceinline__ int64_t dsc_checked_index(int64_t v, int64_t n) {
+// `first`: true for ONE thread per checked value (the caller's first thread of the first block that reads it), so the counter reads
+// as "out-of-range values seen", not threads x blocks per event.
+__device__ __forceinline__ int64_t dsc_checked_index(int64_t v, int64_t n, bool first = true) {
     if (v < 0 || v >= n) {
-        atomicAdd(&dsc_bad_index_count, 1u);
-        return v < 0 ? 0 : n - 1;
+        if (first) atomicAdd(&dsc_bad_index_count, 1u);
+        return (v < 0 || n < 1) ? 0 : n - 1;
     }
     return v;
 }
@@ -146,6 +148,6 @@ static inline unsigned dsc_read_bad_index_count(bool reset) {
 unsigned dsc_bad_index_diffusion(bool reset);
 unsigned dsc_bad_index_train(bool reset);
 // clamp only (GEMM prologues: no counter, no branch)
-__device__ __forceinline__ int64_t dsc_clamp_index(int64_t v, int64_t n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+__device__ __forceinline__ int64_t dsc_clamp_index(int64_t v, int64_t n) { return (v < 0 || n < 1) ? 0 : (v >= n ? n - 1 : v); }    // (n < 1: row 0, never row -1)
 
 static inline bool dsc_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

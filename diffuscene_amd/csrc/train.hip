@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(256) void ddpm_loss_kernel(const LossArgs p) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = p.n, C = p.c;
     const long base = (long)b * N * C;
-    const int64_t tv = dsc_checked_index(p.t[b], p.T);
+    const int64_t tv = dsc_checked_index(p.t[b], p.T, tid == 0);          // one block per scene: one count per out-of-range scene
     const float lw = p.loss_weight[tv];
     const int c_trans = p.tr, c_size = p.tr + p.sz, c_bbox = p.bb, c_class = p.bb + p.nc;
     const int c_obj0 = (p.no == 0) ? c_class - 1 : c_class, c_obj1 = c_class + p.no;

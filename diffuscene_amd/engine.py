@@ -133,7 +133,7 @@ class Plan:
     def gemm_gn(self, a, w, out, bias, gamma, beta, a2=None, ss=None, ss_mode=SS_NONE, residual=None):
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, gamma=gamma, beta=beta, eps=1e-5,
                                tokens_per_scene=self.N, scale_shift=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
-                               ss_index=self.t_in if ss_mode == SS_BY_INDEX else None)
+                               ss_index=self.t_in if (ss is not None and ss_mode == SS_BY_INDEX) else None)
         lay = ops.planes_layout(g, gn=True)
         pl = self.eng.planes_of(w, lay) if lay >= 0 else None
         if pl is not None:

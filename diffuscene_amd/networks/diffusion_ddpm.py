@@ -7,7 +7,7 @@ Same names, signatures, assertion behaviour and RNG draw order as the reference 
   uploaded ONCE per device instead of on every ``_extract`` call (:220,:232,:284,...);
 * ``q_sample`` / v-target and the whole ``p_mean_variance`` + ``p_sample`` chain (:242-352) are single HIP
   kernels (csrc/diffusion.hip), bit-identical to the reference's fp32 expressions;
-* the reverse loops can run as a replayed hipGraph (``graph=True`` or env DSC_GRAPH=1): one captured step
+* the reverse loops run as a replayed hipGraph (default since round 6; ``graph=False`` or env DSC_GRAPH=0 for the eager loop): one captured step
   with a device-resident timestep, replayed T times -- no Python, no launches on the critical path.
 """
 import json
@@ -296,7 +296,7 @@ class GaussianDiffusion:
                       clip_denoised=True, keep_running=False, graph=None):
         """Generate samples, reference :355-371 (draw order: x_T, then one draw per step)."""
         assert isinstance(shape, (tuple, list))
-        if _use_graph(graph, noise_fn):
+        if _use_graph(graph, noise_fn, denoise_fn):
             from ..sampler import graph_sample_loop
             return graph_sample_loop(self, denoise_fn, tuple(shape), device, condition, condition_cross,
                                      clip_denoised, self._total_steps(keep_running), noise_fn)
@@ -336,7 +336,7 @@ class GaussianDiffusion:
         """Scene completion, reference :447-476: every step re-noises the given objects (noise drawn BEFORE the
         model call) and overwrites the first P rows of x_t in place; at t == 0 the clean objects are restored."""
         assert isinstance(shape, (tuple, list))
-        if _use_graph(graph, noise_fn):
+        if _use_graph(graph, noise_fn, denoise_fn):
             from ..sampler import graph_sample_loop
             print('last:', 0, self.num_timesteps, len(self.betas))
             return graph_sample_loop(self, denoise_fn, tuple(shape), device, condition, condition_cross, clip_denoised,
@@ -363,7 +363,7 @@ class GaussianDiffusion:
                               clip_denoised=True, keep_running=False, input_boxes=None, graph=None):
         """Re-arrangement, reference :478-506: diffuse [translation | angle] only, re-assemble at t == 0."""
         assert isinstance(shape, (tuple, list))
-        if _use_graph(graph, noise_fn):
+        if _use_graph(graph, noise_fn, denoise_fn):
             from ..sampler import graph_sample_loop
             sub = (shape[0], shape[1], self.translation_dim + self.angle_dim)
             img_t = graph_sample_loop(self, denoise_fn, sub, device, condition, condition_cross, clip_denoised,
@@ -482,11 +482,19 @@ class GaussianDiffusion:
             return total_bpd_b.mean(), vals_bt_.mean(), prior_bpd_b.mean(), mse_bt_.mean()
 
 
-def _use_graph(graph, noise_fn):
-    if graph is None:
-        graph = os.environ.get("DSC_GRAPH", "0") == "1"
+def _use_graph(graph, noise_fn, denoise_fn=None):
+    """Does this reverse loop run as the replayed hipGraph step (sampler.py)?  ``graph=True`` / ``False`` decide; None (what the
+    reference's call sites pass) = yes by default since round 6 -- the captured loop is bit-identical to the eager one and not
+    host-bound at small batches -- unless DSC_GRAPH=0, a custom ``noise_fn`` (its draws cannot be captured) or a ``denoise_fn`` that
+    is not DiffusionPoint._denoise over this package's Unet1D."""
     from ..sampler import NoiseReplay
-    return bool(graph) and (noise_fn is torch.randn or isinstance(noise_fn, NoiseReplay))
+    capturable = noise_fn is torch.randn or isinstance(noise_fn, NoiseReplay)
+    if graph is None:
+        if os.environ.get("DSC_GRAPH", "1") == "0" or not capturable:
+            return False
+        from .denoise_net import Unet1D
+        return isinstance(getattr(getattr(denoise_fn, "__self__", None), "model", None), Unet1D)
+    return bool(graph) and capturable
 
 
 class DiffusionPoint(nn.Module):

@@ -416,6 +416,8 @@ def train_on_batch(model, optimizer, sample_params, config):
         logger[k].value = v
     logger["gradnorm"].value = packed[1]
     logger["lr"].value = lr
+    from .._lib import check_indices
+    check_indices("train_on_batch")            # DSC_CHECK_INDICES=1: a clamped (out-of-range) device timestep is an error, as in the reference
     return packed[0]
 
 

@@ -79,6 +79,8 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         if tuple(actgrad_x.shape) != (g.m, g.n):
             raise RuntimeError("actgrad_x shape %s != (%d, %d)" % (tuple(actgrad_x.shape), g.m, g.n))
     if ss_index is not None:
+        if scale_shift is None:
+            raise RuntimeError("ss_index (DSC_SS_BY_INDEX) needs the scale_shift table it indexes")
         g.ss_index = _dev(ss_index, "ss_index", torch.int64).data_ptr()
         g.ss_rows = scale_shift.shape[0]              # the device clamps every gathered row into the table
     if w_planes is not None:

@@ -201,6 +201,8 @@ def graph_sample_loop(diff, denoise_fn, shape, device, condition, condition_cros
             out = g.run(x_T, total_steps, partial=partial_boxes)
         if partial_boxes is not None:
             out[:, :partial_boxes.shape[1], :] = partial_boxes          # clean objects restored after the last step (:471-473)
+        from ._lib import check_indices
+        check_indices("graph_sample_loop")     # DSC_CHECK_INDICES=1 (debugging; synchronises)
         return out
 
 

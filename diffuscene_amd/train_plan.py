@@ -236,7 +236,8 @@ class HipBackend:
                 fn = self.lib.fn("dsc_gemm_splitk_f32")
                 floats = splits * m * out.shape[1]
                 g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
-                self.keep.append((g, a, w, out, bias, residual))
+                from .engine import _own
+                self.keep.append(_own((g, a, w, out, bias, residual)))       # the plan owns the storages its raw pointers refer to
                 self.f32_reads.add(w.untyped_storage().data_ptr())
                 return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))
         g = ops.make_gemm_args(a, w, out, bias, a2, residual, ACT_NONE, act_out)
@@ -261,7 +262,8 @@ class HipBackend:
             return None
         fn = self.lib.fn("dsc_gemm_splitk_f32")
         g = ops.make_gemm_args(a, w, out, None, None, residual, ACT_NONE, ACT_NONE)
-        self.keep.append((g, a, w, out, residual))
+        from .engine import _own
+        self.keep.append(_own((g, a, w, out, residual)))
         self.f32_reads.add(w.untyped_storage().data_ptr())
         floats = splits * m * n
         return self._with_scratch(floats, lambda wp, wn: (fn, (C.byref(g), splits, wp, wn), "dsc_gemm_splitk_f32"))

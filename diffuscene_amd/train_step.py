@@ -23,16 +23,71 @@ _PART_KEYS = ('loss.bbox', 'loss.trans', 'loss.size', 'loss.angle', 'loss.class'
 
 
 DDP_FLUSH_SCHEDULES = ("single", "block", "thirds")
+_warned_end = False
 
 
-def ddp_flush_schedule():
-    """The data-parallel flush schedule named by DSC_DDP_FLUSH (PlanRunner.plan_for documents the three); 'end' = 'single'."""
-    flush = os.environ.get("DSC_DDP_FLUSH", "single")
+def ddp_flush_schedule(world=1):
+    """The data-parallel flush schedule named by DSC_DDP_FLUSH (PlanRunner.plan_for documents the three), or 'auto': the runner times
+    all three on the first training steps and keeps the fastest (the default with more than one rank, round 6; a single rank --
+    DSC_DDP_FORCE tests -- defaults to 'single').  'end' is a deprecated alias of 'single' (rounds 4 used it for what is now 'thirds')."""
+    global _warned_end
+    flush = os.environ.get("DSC_DDP_FLUSH", "auto" if world > 1 else "single")
     if flush == "end":
+        if not _warned_end:
+            import warnings
+            warnings.warn("DSC_DDP_FLUSH=end is deprecated: it now means 'single' (no overlap; rounds 1-3) -- round 4 used the name for the "
+                          "three-flush overlap schedule, which is 'thirds' now.  Say 'single', 'block', 'thirds' or 'auto'.", stacklevel=2)
+            _warned_end = True
         flush = "single"
-    if flush not in DDP_FLUSH_SCHEDULES:
-        raise ValueError("DSC_DDP_FLUSH=%r: must be 'single' (default; alias 'end'), 'block' or 'thirds'" % flush)
+    if flush not in DDP_FLUSH_SCHEDULES + ("auto",):
+        raise ValueError("DSC_DDP_FLUSH=%r: must be 'auto', 'single' (alias 'end'), 'block' or 'thirds'" % flush)
     return flush
+
+
+class ScheduleTuner:
+    """DSC_DDP_FLUSH=auto: the data-parallel runner tries every flush schedule on the first training steps -- WARM steps to build, capture
+    and replay the plan, then TIMED steps on the wall clock (start of a step to the start of the next: exchange, clip and Adam
+    included) --, the ranks agree on the per-schedule time with one all_reduce(MAX) each, and every rank keeps the same fastest
+    schedule from then on.  Every step is a real training step under any schedule (same gradients); what the 18 steps cost is two
+    extra plan builds.  ``interval`` (tests) replaces the measured seconds of a step by ``interval(schedule)``."""
+    WARM, TIMED = 3, 3
+
+    def __init__(self, device, interval=None, log=None):
+        self.device, self.interval, self.log = device, interval, log
+        self.order = list(DDP_FLUSH_SCHEDULES)
+        self.i, self.n, self.acc, self.last = 0, 0, 0.0, None
+        self.totals, self.choice = {}, None
+
+    def current(self):
+        return self.choice or self.order[self.i]
+
+    def _now(self):
+        import time
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return time.perf_counter()
+
+    def tick(self):
+        """At the start of every training step while the choice is open."""
+        if self.choice is not None:
+            return
+        import torch.distributed as dist
+        now = self._now()
+        if self.last is not None and self.n > self.WARM:
+            self.acc += (now - self.last) if self.interval is None else self.interval(self.order[self.i])
+        if self.n == self.WARM + self.TIMED:
+            t = torch.tensor([self.acc / self.TIMED], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)              # the slowest rank sets a schedule's step time
+            self.totals[self.order[self.i]] = float(t.item())
+            self.i, self.n, self.acc = self.i + 1, 0, 0.0
+            if self.i == len(self.order):
+                self.choice = min(self.order, key=lambda k: (self.totals[k], self.order.index(k)))
+                if self.log is not None:
+                    self.log("data-parallel flush schedule: %s (%s ms per step, max over ranks)" % (
+                        self.choice, ", ".join("%s %.2f" % (k, 1e3 * self.totals[k]) for k in self.order)))
+            now = self._now()                                     # the next schedule's first step starts its own clock
+        self.n += 1
+        self.last = now
 
 
 def plan_supported(model):
@@ -60,6 +115,7 @@ class PlanRunner:
     # what lowers a plan's ops to launches: HipBackend (libdiffuscene_hip.so).  tests/ substitute the torch backend of
     # tests/plan_sim.py to drive this runner -- plan cache, reducer, segments, broadcast -- under gloo on CPU; the product never does.
     backend_factory = None
+    tuner_interval = None        # tests: seconds of a timed step per schedule instead of the wall clock (ScheduleTuner)
 
     def __init__(self, model):
         self.model = model
@@ -67,6 +123,7 @@ class PlanRunner:
         self.plans = {}                   # insertion-ordered: least recently used first
         self.last_key = None
         self.synced = False
+        self.tuner = None                 # DSC_DDP_FLUSH=auto (default with world > 1): ScheduleTuner
 
     def __deepcopy__(self, memo):         # plans hold ctypes tables and captured graphs: a copied model builds its own
         return None
@@ -84,6 +141,24 @@ class PlanRunner:
         if not (dist.is_available() and dist.is_initialized()):
             return False
         return dist.get_world_size() > 1 or os.environ.get("DSC_DDP_FORCE", "0") == "1"
+
+    def _tuner(self):
+        if self.tuner is None:
+            import torch.distributed as dist
+            rank0 = dist.get_rank() == 0
+
+            def say(msg, rank0=rank0):
+                if rank0:
+                    import sys
+                    print("[diffuscene_amd] " + msg, file=sys.stderr, flush=True)
+            self.tuner = ScheduleTuner(self.flat.device, PlanRunner.tuner_interval, say)
+        return self.tuner
+
+    def begin_step(self, backward):
+        """Start of a training step: with DSC_DDP_FLUSH=auto and more than one rank the schedule tuner takes its clock reading here (and
+        may move on to the next schedule, or settle), before the step's plan is looked up."""
+        if backward and self.distributed() and ddp_flush_schedule(self.world()) == "auto":
+            self._tuner().tick()
 
     def budget_bytes(self):
         """Activation memory all cached plans together may hold (a plan owns every activation and gradient of its signature:
@@ -107,7 +182,9 @@ class PlanRunner:
         #   "end"              alias of "single" (what the name meant up to round 3: the single-GPU schedule, flushed at the end)
         # The default is the cheapest schedule MEASURED: no multi-GPU run exists yet that shows the overlap of "block" paying
         # for its extra launches; `bench.py --gpus N` times all three on the node and uses the fastest.
-        flush = ddp_flush_schedule()
+        flush = ddp_flush_schedule(ws)
+        if flush == "auto":
+            flush = self._tuner().current() if distributed else "single"
         per_block = distributed and flush == "block"
         thirds = distributed and flush == "thirds"
         from ._lib import gemm_mode
@@ -274,6 +351,7 @@ def loss_step(model, sample_params, backward):
     if condition_cross is not None and model.diffusion.model.text_condition:
         L, text_dim = condition_cross.shape[1], condition_cross.shape[2]
         cross_rows = condition_cross.reshape(B * L, text_dim)
+    r.begin_step(backward)
     ent = r.plan_for(B, N, ctx_mode, ctx_dim, L, text_dim, ctx_param)
     plan = ent["plan"]
     with torch.no_grad():

@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -300,6 +301,59 @@ def test_loss_step_runner_path_world2_gloo(tmp_path):
             assert err < 1e-5, (step, err)
     finally:
         undo()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DSC_DDP_FLUSH=auto (the default with more than one rank, round 6): the runner tries the three flush schedules on the first training
+# steps and every rank must settle on the SAME one -- decided on the max over ranks, not on a rank's own clock.
+# ---------------------------------------------------------------------------------------------------------------------
+_FAKE_MS = ({"single": 30.0, "block": 25.0, "thirds": 28.0},      # rank 0 alone would keep "block"
+            {"single": 24.0, "block": 29.0, "thirds": 26.0})      # rank 1 alone would keep "single"; max over ranks: thirds 28 < block 29 < single 30
+
+
+def _tuner_worker(rank, ws, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("DSC_DDP_FLUSH", None)                      # default: auto with world > 1
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    torch.set_num_threads(2)
+    ts, _ = _use_sim_backend()
+    ts.ScheduleTuner.WARM, ts.ScheduleTuner.TIMED = 1, 1       # two steps per schedule instead of six
+    ts.PlanRunner.tuner_interval = staticmethod(lambda schedule: _FAKE_MS[rank][schedule] * 1e-3)
+    m, nc, N = _wrapper_model(tmp, seed=rank)
+    s = _shard(nc, N, 2 * rank, 2 * rank + 2)
+    used = []
+    for step in range(8):
+        torch.manual_seed(70 + step)
+        ts.loss_step(m, s, backward=True)
+        used.append(m._dsc_plan_runner.tuner.current())
+    tuner = m._dsc_plan_runner.tuner
+    torch.save({"choice": tuner.choice, "totals": dict(tuner.totals), "used": used, "G": m._dsc_flat.G.clone(),
+                "plans": len(m._dsc_plan_runner.plans)}, os.path.join(tmp, "tuner_r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_auto_flush_schedule_is_agreed_on_the_slowest_rank(tmp_path):
+    tmp = str(tmp_path)
+    mp.spawn(_tuner_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp, "tuner_r0.pt")), torch.load(os.path.join(tmp, "tuner_r1.pt"))
+    assert r0["choice"] == r1["choice"] == "thirds", (r0["choice"], r1["choice"])
+    assert r0["totals"] == r1["totals"] and abs(r0["totals"]["single"] - 0.030) < 1e-9 and abs(r0["totals"]["block"] - 0.029) < 1e-9
+    assert r0["used"] == r1["used"] == ["single", "single", "block", "block", "thirds", "thirds", "thirds", "thirds"], r0["used"]
+    assert torch.equal(r0["G"], r1["G"]) and r0["plans"] == 3          # one plan per schedule tried; the gradients stay in step
+
+
+def test_flush_schedule_names(monkeypatch):
+    from diffuscene_amd import train_step as ts
+    monkeypatch.delenv("DSC_DDP_FLUSH", raising=False)
+    assert ts.ddp_flush_schedule(1) == "single" and ts.ddp_flush_schedule(8) == "auto"
+    monkeypatch.setenv("DSC_DDP_FLUSH", "end")
+    monkeypatch.setattr(ts, "_warned_end", False)
+    with pytest.warns(UserWarning, match="deprecated"):
+        assert ts.ddp_flush_schedule(8) == "single"
+    monkeypatch.setenv("DSC_DDP_FLUSH", "bogus")
+    with pytest.raises(ValueError):
+        ts.ddp_flush_schedule(2)
 
 
 def test_failed_capture_is_not_retried_every_step(tmp_path, monkeypatch):

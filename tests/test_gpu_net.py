@@ -115,6 +115,36 @@ def test_scripts_graph_switch_env(monkeypatch):
     assert calls and torch.isfinite(s).all()
 
 
+def test_default_loop_is_the_captured_graph_and_draws_like_the_eager_loop(monkeypatch):
+    """Round 6: a reverse loop called the way the reference's scripts call it (no ``graph`` argument, default ``noise_fn``) replays the
+    captured step; under the same ``torch.manual_seed`` it draws the same numbers as the eager loop (``graph=False`` / DSC_GRAPH=0) and
+    returns the same scenes bit for bit.  A custom ``noise_fn`` stays eager."""
+    from diffuscene_amd import sampler
+    calls = []
+    orig = sampler.graph_sample_loop
+    monkeypatch.setattr(sampler, "graph_sample_loop", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.delenv("DSC_GRAPH", raising=False)
+    net, diff = build("uncond_bedroom", time_num=6, model_mean_type="v")
+    cond = W.synth_condition(3, 12, 128, seed=2).to(dev())
+    with torch.no_grad():
+        torch.manual_seed(11)
+        yg = diff.gen_samples((3, 12, 62), dev(), condition=cond, clip_denoised=True)
+        assert len(calls) == 1
+        torch.manual_seed(11)
+        ye = diff.gen_samples((3, 12, 62), dev(), condition=cond, clip_denoised=True, graph=False)
+        assert len(calls) == 1
+        monkeypatch.setenv("DSC_GRAPH", "0")
+        torch.manual_seed(11)
+        y0 = diff.gen_samples((3, 12, 62), dev(), condition=cond, clip_denoised=True)
+        assert len(calls) == 1
+        monkeypatch.delenv("DSC_GRAPH")
+        diff.gen_samples((3, 12, 62), dev(), condition=cond, clip_denoised=True,
+                         noise_fn=lambda size, dtype, device: torch.zeros(size, dtype=dtype, device=device))
+        assert len(calls) == 1
+    assert torch.equal(ye, y0)
+    assert torch.equal(yg, ye), "captured loop and eager loop differ under the same seed: %g" % float((yg - ye).abs().max())
+
+
 def _replay(seq):
     from diffuscene_amd.sampler import NoiseReplay
     return NoiseReplay(torch.stack(seq).to(dev()))
