@@ -383,7 +383,10 @@ def roofline_dominant_kernel(plan, N, config_name):
     mult, peak = (SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS) if split else (1, PEAK_FP32_MFMA_TFLOPS)
     alg = flops / (ms * 1e-3) / 1e12
     alg_mix = flops_mix / (ms_mix * 1e-3) / 1e12
-    kname = ("dsc_split::gemm_split_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; 3xbf16 split, 6 MFMA products)" % M
+    tile = _lib.fn("dsc_gemm_split_tile")(sel512[0][0], 1)             # ... and which kernel family / tile it picks
+    wave = tile in (_lib.TILE_WAVE_GN, _lib.TILE_WAVE_DENSE)
+    kname = (("dsc_wave::gemm_split_wave_kernel<GN=true> (wave-autonomous, tile %d; " % tile if wave else "dsc_split::gemm_split_kernel<GN=true> (block-staged, tile %d; " % tile)
+             + "WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; 3xbf16 split, 6 MFMA products)" % M
              if split else "dsc_gemm::gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; f32 MFMA)" % M)
     # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, separate passes:
     # tools/gpu_round.sh pmc + tools/pmc_summary.py on the same workload -- bench.py cannot run the profiler on itself).  The file
@@ -397,7 +400,7 @@ def roofline_dominant_kernel(plan, N, config_name):
         with open(path) as f:
             rec = json.load(f)
         if (M != 20480 or rec.get("csrc_sha") != here or "hbm_bytes_per_launch" not in rec
-                or ("gemm_split" in (rec.get("kernel") or "")) != split):
+                or ("gemm_split" in (rec.get("kernel") or "")) != split or (split and ("gemm_split_wave" in (rec.get("kernel") or "")) != wave)):
             continue
         traffic = round(rec["hbm_bytes_per_launch"])
         traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; csrc %s, git %s; per-launch average over the K=512 " \

@@ -158,8 +158,9 @@ SIGNATURES = {
     "dsc_gemm_tn_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int64, C.c_int64,
                                           C.c_void_p]),
     "dsc_gemm_tn_grouped_split_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, c_f32p, C.c_int64,
-                                                C.c_int64, C.c_void_p]),
+                                                C.c_int64, C.c_int32, C.c_void_p]),
     "dsc_set_tn_split_form": (C.c_int, [C.c_int32]),
+    "dsc_get_tn_split_form": (C.c_int, []),
     "dsc_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "dsc_colsum_grouped_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dsc_gn_silu_bwd_f32": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32,
@@ -225,6 +226,8 @@ def load():
         fn.argtypes = args
     if lib.dsc_get_gemm_arithmetic() < 0:
         raise ValueError("DSC_GEMM=%r: must be 'split' (default) or 'f32'" % os.environ.get("DSC_GEMM"))
+    if lib.dsc_get_tn_split_form() < 0:
+        raise ValueError("DSC_TN_FORM=%r: must be '2' (default), '1' or '0'" % os.environ.get("DSC_TN_FORM"))
     if lib.dsc_get_split_wave() < 0:
         raise ValueError("DSC_WAVE=%r: must be '1' / 'auto' (default) or '0'" % os.environ.get("DSC_WAVE"))
     _lib = lib
@@ -242,7 +245,9 @@ def gemm_mode():
     kernel only, 2 = split-bf16 with the wave-autonomous kernel wherever a launch qualifies (default).  They are keyed by it and
     rebuilt on their next use after a switch."""
     lib = load()
-    return 0 if lib.dsc_get_gemm_arithmetic() != 1 else (2 if lib.dsc_get_split_wave() == 1 else 1)
+    if lib.dsc_get_gemm_arithmetic() != 1:
+        return 0
+    return (2 if lib.dsc_get_split_wave() == 1 else 1) + 10 * lib.dsc_get_tn_split_form()     # (+ the weight-gradient tile form: plans bake its block map in)
 
 
 def set_split_wave(on):

@@ -11,6 +11,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DSC_WAVE 64
 
+#include <utility>
+template <class F, int... I>
+__device__ __forceinline__ void dsc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order: compile-time indices for hand-placed instruction streams
+template <int N, class F>
+__device__ __forceinline__ void dsc_static_for(F&& f) { dsc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // hipGetLastError() is per-thread and sticky: another library (PyTorch probing devices while it initialises) can leave
 // an unrelated error behind.  Flush it before our launch so DSC_LAUNCH_CHECK reports only this launch.
 #define DSC_CLEAR_STALE_ERROR() ((void)hipGetLastError())

@@ -11,9 +11,12 @@
 //
 // Measured on MI355X against an f64 product (profiles/r03_bf16x6_*.txt): max / rms error <= those of the exact-f32 MFMA kernel at
 // K = 128 .. 3072 (the MFMA sums 32 products per instruction before it rounds into the accumulator: 16 roundings per K = 512
-// instead of 256).  The bf16 pipe is 16x the f32-MFMA rate, six products are 2.67x the f32-MFMA roofline; sustained, the chip's power
-// management holds the K loop at ~1.25 PFLOP/s executed, i.e. ~1.5x the f32-MFMA kernel per launch (79.5 -> 52.7 us at
-// M = 20480, n = K = 512).
+// instead of 256).  The bf16 pipe is 16x the f32-MFMA rate, six products are 2.67x the f32-MFMA roofline; measured, the launch runs at
+// ~1.5x the f32-MFMA kernel (79.5 -> 52.7 us at M = 20480, n = K = 512) with the matrix cores busy 0.43 of the time AT FULL CLOCK
+// (GRBM_GUI_ACTIVE / 8 over the duration = 2.36 GHz, profiles/r05_gemm_gn_hbm_traffic.json): the K loop of this block-staged form is
+// issue- and barrier-bound (77 % issue efficiency inside the loop, ~20 % exposed prologue + store burst), not power-bound -- only the
+// grouped weight-gradient launch is throttled (1.86 GHz at busy 0.68).  Round 6 adds the wave-autonomous family (gemm_split_wave.h):
+// same arithmetic bit for bit, no block barrier, row-layout epilogue; it takes the launches that come out at whole waves per SIMD.
 //
 // Layout (the best of the forms measured in round 3, "PIPE 3" of the experiment): 8 waves as WM x WN; a wave owns ONE scene (<= 16*RB
 // tokens, padded to RB MFMA row blocks inside LDS) x 64 channels = RB x 4 MFMA blocks of 16 x 16 -- exactly one GroupNorm cell, so the
@@ -416,7 +419,7 @@ __device__ __forceinline__ void gemm_split_tile(const dsc_gemm_args& p, const in
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 s0 += valid[i] ? (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]) : 0.f;
-        const float mean = wave_sum(s0) * inv_cnt;
+        const float mean = wave_sum_dpp(s0) * inv_cnt;
         float q0 = 0.f;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -427,7 +430,7 @@ __device__ __forceinline__ void gemm_split_tile(const dsc_gemm_args& p, const in
                     const float d = valid[i] ? acc[i][j][e] - mean : 0.f;
                     q0 = fmaf(d, d, q0);
                 }
-        const float rstd = 1.f / sqrtf(wave_sum(q0) * inv_cnt + p.eps);
+        const float rstd = 1.f / sqrtf(wave_sum_dpp(q0) * inv_cnt + p.eps);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -66,12 +66,6 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8& p
     p3 = __builtin_bit_cast(bf16x8, c);
 }
 
-template <class F, int... I>
-__device__ __forceinline__ void dsc_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
-template <int N, class F>
-__device__ __forceinline__ void dsc_static_for(F&& f) { dsc_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
 template <int RB>
 constexpr int wave_smem_bytes() { return WAVES * 2 * 3 * (16 * RB) * 64; }
 
@@ -425,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
                     const float t = (a[0] + a[1]) + (a[2] + a[3]);
                     s0 += (i < RB - 1 || vlast) ? t : 0.f;
                 }
-            const float mean = wave_sum(s0) * inv_cnt;
+            const float mean = wave_sum_dpp(s0) * inv_cnt;
             float q0 = 0.f;
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -436,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
                         const float d = (i < RB - 1 || vlast) ? acc[i][4 * c2 + j][e] - mean : 0.f;
                         q0 = fmaf(d, d, q0);
                     }
-            const float rstd = 1.f / sqrtf(wave_sum(q0) * inv_cnt + p.eps);
+            const float rstd = 1.f / sqrtf(wave_sum_dpp(q0) * inv_cnt + p.eps);
             if (c2 == 0) { DSC_WAVE_STAMP_KERNEL(3) }
             f32x4 A, B;                                   // y = z * A + B with A = rstd*gamma*(scale+1), B = (beta - mean*rstd*gamma)*(scale+1) + shift
 #pragma unroll

@@ -545,4 +545,248 @@ __device__ __forceinline__ void tn_split_block_ws(const Prob& p, const int it, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the 256 x 256 block tile.  Rounds 4 / 5 showed the token step of the 256 x 128 tile bound by the BYTES it moves per MFMA --
+// through the vector-memory path, the LDS writes and the fragment reads -- whoever issues them (producer waves at the MFMA floor when
+// nothing is staged; every ingredient of the staging costs its full time).  This body halves them: four waves, ONE per SIMD with the
+// 512-register budget, wave tile 128 n x 128 k = 8 x 8 MFMA blocks (256 accumulator registers); per step and block 64 KiB of operand
+// rows for 1536 MFMAs (48 KiB for 768 before), 48 fragment reads per 384 MFMAs and wave (36 per 192).  A wave holds the 24 dY
+// fragments of the step and streams the x fragments per k block; the staging (the same (channel pair, token octet) items, the same
+// exact split, the same LDS image, the same per-item bias partial sums) rides between the wave's own MFMAs, placed by hand (one MFMA,
+// one filler, one scheduling barrier -- as in gemm_split_wave.h), one step ahead.
+// LDS: two stages of the first two piece planes (4 x 32 KiB) and ONE buffer for the third-piece plane (32 KiB) = all 160 KiB.  The
+// third pieces only enter the first two products of a block (x3 d1, x1 d3): by the last k block of a step every wave has read the last
+// x3 fragment and holds its d3 fragments in registers, so a barrier there frees the plane and the next step's third pieces -- kept in
+// 32 registers until then -- are written under the last k block's MFMAs.  Two barriers per step, no exposed write phase.
+// Every accumulator sees the same six products per token step in the same order as in the other two bodies: bit-identical dW and bias
+// gradients (tests/test_gpu_train.py holds the three to each other).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int BBN = 256, BBK = 256, BCOLS = BBN + BBK, BT = 256;
+constexpr int BPLANE = BCOLS * BMS * 2;               // 32768 B: one bf16 plane of the 512 staged channels
+constexpr int BSMEM = 5 * BPLANE;                     // 163840 B = the whole LDS
+constexpr int BITEMS = (BCOLS / 2) * 4 / BT;          // 4 (channel pair, token octet) items per lane and step: lane = pair, item = octet
+
+__device__ __forceinline__ void tn_split_block_big(const Prob& p, const int it, const int jt, const int split, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave_u & 1, wk = wave_u >> 1;
+    const int n0 = jt * BBN, k0 = it * BBK;
+    const long m_begin = (long)split * p.chunk;
+    const long m_end = (m_begin + p.chunk < p.m) ? m_begin + p.chunk : p.m;
+    const int steps = m_end > m_begin ? (int)((m_end - m_begin + BMS - 1) / BMS) : 0;
+    const bool do_bias = p.bias_out != nullptr && it == 0;
+    const int g = lane >> 4, l15 = lane & 15;
+
+    // operands of this tile (a k tile never straddles the two K segments: k1 % 256 == 0 when k2 > 0, checked by the host)
+    const bool seg1 = k0 < p.k1;
+    const float* const xbase = seg1 ? p.a1 + k0 : p.a2 + (k0 - p.k1);
+    const long ldx = seg1 ? p.lda1 : p.lda2;
+    const int xcols = seg1 ? p.k1 - k0 : p.k1 + p.k2 - k0;
+    const float* const dbase = p.dy + n0;
+    const int dcols = p.n - n0;
+    // lane = channel pair: waves 0, 1 stage the 256 dY channels, waves 2, 3 the 256 x channels (wave-uniform)
+    const bool isdy = wave_u < 2;
+    const int pr = tid, c = isdy ? 2 * pr : 2 * pr - BBN;                       // channel inside its operand
+    const int cc = isdy ? (c < dcols ? c : 0) : (c < xcols ? c : 0);            // past the edge: channel 0 (its products are never stored)
+    const long ldop = isdy ? p.ldd : ldx;
+#if defined(__HIP_DEVICE_COMPILE__)
+    long xrec = ((long)(p.m - 1) * ldx + xcols) * 4, drec = ((long)(p.m - 1) * p.ldd + dcols) * 4;
+    if (xrec > 0x7fffffffL) xrec = 0x7fffffffL;
+    if (drec > 0x7fffffffL) drec = 0x7fffffffL;
+    const __amdgpu_buffer_rsrc_t rop = isdy ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dbase), 0, (int)drec, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xbase), 0, (int)xrec, 0x00020000);
+#endif
+    // item u = token octet u of this lane's channel pair: rows 8 u .. 8 u + 7 of the step (through the scalar offset of the loads);
+    // LDS channel 2 pr (2 pr + 1 sits 64 bytes on), octet slot u ^ (pr & 3)
+    const int ivoff0 = cc * 4;
+    int ildso[BITEMS];
+#pragma unroll
+    for (int u = 0; u < BITEMS; ++u) ildso[u] = 2 * pr * 64 + ((u ^ (pr & 3)) << 4);
+    float bsum[BITEMS][2];
+    float ld[BITEMS][2][8];                                                     // [item][channel of the pair][token]
+    u32x4 hold3[BITEMS][2];                                                     // third pieces of the NEXT step, until the plane is free
+#pragma unroll
+    for (int u = 0; u < BITEMS; ++u) bsum[u][0] = bsum[u][1] = 0.f;
+    auto load_item = [&](int u, int step) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const long mb = m_begin + (long)step * BMS;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rop, ivoff0, (int)((mb + 8 * u + e) * ldop * 4), 0);
+            const unsigned lo = v[0], hi = v[1];
+            ld[u][0][e] = __builtin_bit_cast(float, lo);
+            ld[u][1][e] = __builtin_bit_cast(float, hi);
+        }
+#else
+        (void)u; (void)step;
+#endif
+    };
+    auto clampi = [&](int st) { return st < steps ? st : steps - 1; };
+    char* const s3 = smem + 4 * BPLANE;                                         // the third-piece plane
+
+    // fragment offsets inside a plane: x (row operand) channel 256 + wk*128 + kb*16 + l15; dY (column operand) channel wn*128 + nb*16 + l15
+    // (block b of 16 channels sits 1024 bytes on; the octet swizzle only depends on l15: every block start is a multiple of 8 channels)
+    const int xoff0 = (BBN + wk * 128 + l15) * 64 + ((g ^ ((l15 >> 1) & 3)) << 4);
+    const int doff0 = (wn * 128 + l15) * 64 + ((g ^ ((l15 >> 1) & 3)) << 4);
+    auto xoff = [&](int b) { return xoff0 + b * 1024; };
+    auto doff = [&](int b) { return doff0 + b * 1024; };
+    f32x4 acc[8][8];                                                            // [kb][nb]
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (steps > 0) {                                                            // prologue: step 0 whole, the rows of step 1 requested
+#pragma unroll
+        for (int u = 0; u < BITEMS; ++u) load_item(u, 0);
+#pragma unroll
+        for (int u = 0; u < BITEMS; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float (&x)[8] = ld[u][h];
+                if (do_bias && isdy) bsum[u][h] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                bf16x8 a, b, cpl;
+                split8(x, a, b, cpl);
+                *reinterpret_cast<bf16x8*>(smem + ildso[u] + 64 * h) = a;
+                *reinterpret_cast<bf16x8*>(smem + BPLANE + ildso[u] + 64 * h) = b;
+                *reinterpret_cast<bf16x8*>(s3 + ildso[u] + 64 * h) = cpl;
+            }
+#pragma unroll
+        for (int u = 0; u < BITEMS; ++u) load_item(u, clampi(1));
+    }
+    const float cnt_flag = (do_bias && isdy) ? 1.f : 0.f;
+    for (int s = 0; s < steps; ++s) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): my plane writes of this step are done
+        __syncthreads();                                  // everyone's are (first two planes of stage s & 1, the third-piece plane)
+        char* const cur = smem + (s & 1) * 2 * BPLANE;    // planes 1, 2 of this step; plane 3 at s3
+        char* const nxt = smem + ((s + 1) & 1) * 2 * BPLANE;
+        const bool more = s + 1 < steps;
+        const float cnt = more ? cnt_flag : 0.f;          // rows past the end are duplicates: never counted into the bias sums
+        const int s2 = clampi(s + 2);
+        auto plane = [&](char* base12, int pl) -> char* { return pl < 2 ? base12 + pl * BPLANE : s3; };
+        // fragments of the step, in the order the first MFMAs consume them: x3 | d1 x 8 | x1 | d3 x 8 | x2 | d2 x 8
+        bf16x8 df[8][3], xf[2][3];
+        xf[0][2] = *reinterpret_cast<const bf16x8*>(plane(cur, 2) + xoff(0));
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) df[nb][0] = *reinterpret_cast<const bf16x8*>(plane(cur, 0) + doff(nb));
+        xf[0][0] = *reinterpret_cast<const bf16x8*>(plane(cur, 0) + xoff(0));
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) df[nb][2] = *reinterpret_cast<const bf16x8*>(plane(cur, 2) + doff(nb));
+        xf[0][1] = *reinterpret_cast<const bf16x8*>(plane(cur, 1) + xoff(0));
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) df[nb][1] = *reinterpret_cast<const bf16x8*>(plane(cur, 1) + doff(nb));
+        __builtin_amdgcn_sched_barrier(0);
+        auto kblock = [&](auto kbc) {
+            constexpr int kb = decltype(kbc)::value;
+            constexpr int u = kb >> 1, h = kb & 1;        // this block splits channel h of item u (the rows of step s + 1)
+            constexpr int NR = kb < 7 ? 3 : 0;            // fragment reads of the next k block
+            constexpr int S0 = NR, S1 = S0 + 22, S2 = S1 + 5, S3 = S2 + 2, S4 = S3 + (h ? 8 : 0), S5 = S4 + (kb == 7 ? 8 : 0);
+            static_assert(S5 <= 48, "one MFMA per filler slot");
+            if constexpr (kb == 7) {
+                // every wave has read the last third-piece fragments (x3 of k block 7 came in under block 6): the plane is free
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __syncthreads();
+            }
+            unsigned su1[4], su2[4], su3[4];
+            float sr0[4], sr1[4], st0[4], st1[4], bs0, bs1, bs2, bs3;
+            const float (&x)[8] = ld[u][h];
+            auto split_op = [&](auto nc) {
+                constexpr int n = decltype(nc)::value;                      // 0..43: pairs (0,1) interleaved, then (2,3)
+                constexpr int q = 2 * (n / 22) + (n & 1), o = (n % 22) >> 1;
+                if constexpr (o == 0) su1[q] = cvt_pk_bf16(x[2 * q], x[2 * q + 1]);
+                if constexpr (o == 1) st0[q] = bf_lo(su1[q]);
+                if constexpr (o == 2) st1[q] = bf_hi(su1[q]);
+                if constexpr (o == 3) sr0[q] = x[2 * q] - st0[q];
+                if constexpr (o == 4) sr1[q] = x[2 * q + 1] - st1[q];
+                if constexpr (o == 5) su2[q] = cvt_pk_bf16(sr0[q], sr1[q]);
+                if constexpr (o == 6) st0[q] = bf_lo(su2[q]);
+                if constexpr (o == 7) st1[q] = bf_hi(su2[q]);
+                if constexpr (o == 8) sr0[q] = sr0[q] - st0[q];
+                if constexpr (o == 9) sr1[q] = sr1[q] - st1[q];
+                if constexpr (o == 10) su3[q] = cvt_pk_bf16(sr0[q], sr1[q]);
+            };
+            auto filler = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < S0) {
+                    constexpr int pl = k == 0 ? 2 : k == 1 ? 0 : 1;         // x3 first: the next block opens with it
+                    xf[(kb + 1) & 1][pl] = *reinterpret_cast<const bf16x8*>(plane(cur, pl) + xoff(kb < 7 ? kb + 1 : 7));
+                } else if constexpr (k < S1) {
+                    split_op(std::integral_constant<int, 2 * (k - S0)>{});
+                    split_op(std::integral_constant<int, 2 * (k - S0) + 1>{});
+                } else if constexpr (k < S2) {                              // bias partial sum of this (channel, octet): same association as the other bodies
+                    constexpr int j = k - S1;
+                    if constexpr (j == 0) { bs0 = x[0] + x[1]; bs1 = x[2] + x[3]; }
+                    if constexpr (j == 1) { bs2 = x[4] + x[5]; bs3 = x[6] + x[7]; }
+                    if constexpr (j == 2) { bs0 = bs0 + bs1; bs2 = bs2 + bs3; }
+                    if constexpr (j == 3) bs0 = bs0 + bs2;
+                    if constexpr (j == 4) bsum[u][h] = cnt != 0.f ? bsum[u][h] + bs0 : bsum[u][h];
+                } else if constexpr (k < S3) {
+                    constexpr int pl = k - S2;
+                    const u32x4 v = pl == 0 ? u32x4{su1[0], su1[1], su1[2], su1[3]} : u32x4{su2[0], su2[1], su2[2], su2[3]};
+                    *reinterpret_cast<u32x4*>(nxt + pl * BPLANE + ildso[u] + 64 * h) = v;
+                    if constexpr (pl == 1) hold3[u][h] = u32x4{su3[0], su3[1], su3[2], su3[3]};
+                } else if constexpr (k < S4) {
+                    // both channels of item u are split: its registers take the rows of step s + 2
+#if defined(__HIP_DEVICE_COMPILE__)
+                    constexpr int e = k - S3;
+                    const long mb = m_begin + (long)s2 * BMS;
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rop, ivoff0, (int)((mb + 8 * u + e) * ldop * 4), 0);
+                    const unsigned lo = v[0], hi = v[1];
+                    ld[u][0][e] = __builtin_bit_cast(float, lo);
+                    ld[u][1][e] = __builtin_bit_cast(float, hi);
+#endif
+                } else if constexpr (k < S5) {
+                    constexpr int w = k - S4;                               // the eight third pieces of the next step, plane now free
+                    *reinterpret_cast<u32x4*>(s3 + ildso[w >> 1] + 64 * (w & 1)) = hold3[w >> 1][w & 1];
+                }
+            };
+            auto product = [&](auto pc) {
+                constexpr int prd = decltype(pc)::value;
+                constexpr int xp = prd == 0 ? 2 : (prd == 1 || prd >= 4) ? 0 : 1;                              // x3, x1, x2, x2, x1, x1
+                constexpr int dp = prd == 0 ? 0 : prd == 1 ? 2 : prd == 2 ? 1 : prd == 3 ? 0 : prd == 4 ? 1 : 0;   // d1, d3, d2, d1, d2, d1
+                dsc_static_for<8>([&](auto nbc) {
+                    constexpr int nb = decltype(nbc)::value;
+                    acc[kb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kb & 1][xp], df[nb][dp], acc[kb][nb], 0, 0, 0);
+                    filler(std::integral_constant<int, prd * 8 + nb>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            dsc_static_for<6>(product);
+        };
+        dsc_static_for<8>(kblock);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+
+    float* out = p.out + (long)split * p.slab;
+    if (do_bias) {
+        // every dY channel has four items (token octets) in one lane: partial sums through LDS, summed in the order of the other bodies
+        float* bs = reinterpret_cast<float*>(smem);
+        __syncthreads();
+        if (isdy) {
+#pragma unroll
+            for (int u = 0; u < BITEMS; ++u) { bs[u * BBN + 2 * pr] = bsum[u][0]; bs[u * BBN + 2 * pr + 1] = bsum[u][1]; }
+        }
+        __syncthreads();
+        if (tid < BBN && n0 + tid < p.n)
+            p.bias_out[(long)split * p.bias_slab + n0 + tid] = (bs[tid] + bs[BBN + tid]) + (bs[2 * BBN + tid] + bs[3 * BBN + tid]);
+    }
+    const bool vec = (p.ldo & 3) == 0 && (p.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+        const int j = n0 + wn * 128 + nb * 16 + l15;
+        if (j >= p.n) continue;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            const int i = k0 + wk * 128 + kb * 16 + 4 * g;
+            if (vec && i + 3 < p.kvalid) {
+                *reinterpret_cast<f32x4*>(out + (long)j * p.ldo + i) = acc[kb][nb];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i + e < p.kvalid) out[(long)j * p.ldo + i + e] = acc[kb][nb][e];
+            }
+        }
+    }
+}
+
 }  // namespace dsc_tn_split

@@ -3,6 +3,8 @@
 // issue slots), which the other backward kernels of train.hip should not inherit.
 #include "gemm_tn_split.h"
 #include <atomic>
+#include <cstdlib>
+#include <cstring>
 
 #ifndef DSC_TN_NCW
 #define DSC_TN_NCW 4          // consumer waves of the producer / consumer form: 4 (64 x 128 wave tiles, 512 threads: product) or 8 (64 x 64, 768 threads)
@@ -72,23 +74,71 @@ __global__ __launch_bounds__(DSC_TN_WS_THREADS, 1) void gemm_tn_split_grouped_ws
     dsc_tn_split::tn_split_block_ws<DSC_TN_NCW>(p, local % ktiles, local / ktiles, split, smem);
 }
 
-// Which block body the split-bf16 weight-gradient launch runs: 1 = producer / consumer waves (round 5, default), 0 = the round-4 block
-// (every wave stages and multiplies).  Identical results; the switch exists so that a test can hold the two to each other bit for bit.
-static std::atomic<int> g_tn_form{DSC_TN_WS ? 1 : 0};
+// Round 6: 256 x 256 tiles, four waves with the 512-register budget (gemm_tn_split.h, tn_split_block_big); the block map addresses
+// 256-wide k tiles (tile_k = 256 in the launch).
+__global__ __launch_bounds__(dsc_tn_split::BT, 1) void gemm_tn_split_grouped_big_kernel(const dsc_tn_group* __restrict__ groups,
+                                                                                         const int2* __restrict__ block_map, const int splits,
+                                                                                         float* __restrict__ workspace) {
+    __shared__ __attribute__((aligned(16))) char smem[dsc_tn_split::BSMEM];
+    const int2 gt = block_map[blockIdx.x];
+    if (gt.x < 0) return;
+    const dsc_tn_group g = groups[gt.x];
+    const int K = g.k1 + g.k2;
+    const int ktiles = (K + 255) / 256;
+    const int local = gt.y;
+    const int split = blockIdx.y;
+    dsc_tn_split::Prob p;
+    p.a1 = g.a1; p.lda1 = g.lda1; p.k1 = g.k1; p.a2 = g.a2; p.lda2 = g.lda2; p.k2 = g.k2; p.dy = g.dy; p.ldd = g.ldd;
+    p.m = g.m; p.n = g.n; p.kvalid = g.kvalid;
+    p.chunk = ((g.m + splits - 1) / splits + 31) / 32 * 32;
+    if (splits == 1) {
+        p.out = g.out; p.ldo = g.ldo; p.bias_out = g.dbias; p.slab = 0; p.bias_slab = 0;
+    } else {
+        const long wslab = (long)g.n * g.kvalid;
+        p.out = workspace + g.ws_offset; p.ldo = g.kvalid; p.slab = wslab;
+        p.bias_out = g.dbias ? workspace + g.ws_offset + wslab * splits : nullptr; p.bias_slab = g.n;
+    }
+    dsc_tn_split::tn_split_block_big(p, local % ktiles, local / ktiles, split, smem);
+}
+
+// Which block body the split-bf16 weight-gradient launch runs: 2 = 256 x 256 tiles, four waves with the 512-register budget (round 6,
+// default); 1 = 256 x 128 tiles with producer / consumer waves (round 5); 0 = the round-4 block (every wave stages and multiplies).
+// Identical results; the switch exists so that a test can hold the three to each other bit for bit.  The tile width is baked into the
+// host's block map, so the LAUNCH says which numbering its map uses (tile_k); the form picks the body among those of that width.
+// Initial value: DSC_TN_FORM in the environment ("", "2" -> 2; "1"; "0"; anything else -> 2 is NOT assumed: the launch fails).
+static std::atomic<int> g_tn_form{-1000};
+static int tn_form() {
+    int f = g_tn_form.load(std::memory_order_relaxed);
+    if (f == -1000) {
+        const char* e = getenv("DSC_TN_FORM");
+        f = (!e || !e[0] || !strcmp(e, "2")) ? 2 : !strcmp(e, "1") ? 1 : !strcmp(e, "0") ? 0 : DSC_EINVAL;
+        g_tn_form.store(f, std::memory_order_relaxed);
+    }
+    return f;
+}
+extern "C" int dsc_get_tn_split_form(void) { return tn_form(); }
 extern "C" int dsc_set_tn_split_form(int32_t form) {
-    if (form != 0 && form != 1) return DSC_EINVAL;
-    return g_tn_form.exchange(form, std::memory_order_relaxed);
+    if (form < 0 || form > 2) return DSC_EINVAL;
+    const int prev = tn_form();
+    g_tn_form.store(form, std::memory_order_relaxed);
+    return prev;
 }
 
 extern "C" int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles,
                                              const int32_t* block_map_dev, int32_t blocks, int32_t splits, float* workspace,
-                                             int64_t workspace_floats, int64_t workspace_needed, dsc_stream_t stream) {
+                                             int64_t workspace_floats, int64_t workspace_needed, int32_t tile_k, dsc_stream_t stream) {
     if (!groups_dev || !block_map_dev || count < 1 || total_tiles < count || blocks < count || splits < 1 || splits > 64) return DSC_EINVAL;
+    if (tile_k != 128 && tile_k != 256) return DSC_EINVAL;
     if (reinterpret_cast<uintptr_t>(block_map_dev) & 7) return DSC_EALIGN;
     if (splits > 1 && (!workspace || workspace_floats < workspace_needed || workspace_needed < 1)) return DSC_EINVAL;
+    const int form = tn_form();
+    if (form < 0) return DSC_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DSC_CLEAR_STALE_ERROR();
-    if (g_tn_form.load(std::memory_order_relaxed))
+    if (tile_k == 256)
+        hipLaunchKernelGGL(gemm_tn_split_grouped_big_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(dsc_tn_split::BT), 0, s, groups_dev,
+                           reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
+    else if (form != 0)
         hipLaunchKernelGGL(gemm_tn_split_grouped_ws_kernel, dim3((unsigned)blocks, (unsigned)splits), dim3(DSC_TN_WS_THREADS), 0, s, groups_dev,
                            reinterpret_cast<const int2*>(block_map_dev), splits, workspace);
     else

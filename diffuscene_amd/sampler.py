@@ -118,7 +118,11 @@ class _StepGraph:
                          tb["posterior_mean_coef2"], sigma, mean_type, clip_denoised, out=self.x)
             ops.add_scalar_i64(self.t, -1)
 
-        # warm-up on a side stream (loads every code object, sizes the allocator), then capture
+        # warm-up on a side stream (loads every code object, sizes the allocator), then capture.  Building the graph must not cost the
+        # caller random numbers: the loop is the default path behind the reference's call sites (round 6), and a run seeded with
+        # torch.manual_seed has to draw what the eager loop draws whether or not this call had to capture first -- the device
+        # generator's state is put back afterwards (the warm-up step and normal_() below draw from it).
+        rng_state = torch.cuda.get_rng_state(device)
         self.x.normal_()
         self.t.fill_(1)
         if replay:
@@ -133,6 +137,7 @@ class _StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             step()
+        torch.cuda.set_rng_state(rng_state, device)
 
     def check_current(self):
         """The captured launches hold raw pointers into the parameter storages of capture time.  If the parameters have moved since

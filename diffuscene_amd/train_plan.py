@@ -48,7 +48,7 @@ class H:
 
 
 # ======================================================================================================================
-def tn_token_slices(groups, tile_n, blocks_target):
+def tn_token_slices(groups, tile_n, blocks_target, tile_k=128):
     """Token slices of one grouped weight-gradient launch.  groups: (m tokens, n, k) per layer; tile_n x 128 output tiles;
     blocks_target: how many blocks the long tiles should make (rounds x resident blocks).  -> (splits, m_ref).
 
@@ -58,7 +58,7 @@ def tn_token_slices(groups, tile_n, blocks_target):
     850 bulk tiles into 32 slices of 48 tokens each -- 3.7 GB of slabs per step, 5.0 of its 12.2 ms.)  A slice is never shorter than
     256 tokens of the bulk: below that the slab traffic outweighs the parallelism."""
     def tiles(n, k):
-        return ((n + tile_n - 1) // tile_n) * ((k + 127) // 128)
+        return ((n + tile_n - 1) // tile_n) * ((k + tile_k - 1) // tile_k)
     work = {}
     for m, n, k in groups:
         work[m] = work.get(m, 0) + tiles(n, k) * m
@@ -73,8 +73,8 @@ def long_k_splits(K):
     return next((s for s in range(64, 1, -1) if K % (32 * s) == 0 and K // s >= 256), 0)
 
 
-def tn_block_map(groups, n_xcd=8):
-    """Block placement of one grouped weight-gradient launch on the split-bf16 kernel (256 x 128 tiles).
+def tn_block_map(groups, n_xcd=8, tile_k=128):
+    """Block placement of one grouped weight-gradient launch on the split-bf16 kernel (256 x tile_k tiles: 128, or 256 for the round-6 body).
     groups: (m tokens, n, k) per group, in table order.  -> list of (group, tile of the group) per PHYSICAL block id, (-1, -1) = idle.
 
     Consecutive workgroup ids are dealt round-robin over the XCDs (id % 8), each with its own L2, and the tiles of one layer share its
@@ -83,7 +83,7 @@ def tn_block_map(groups, n_xcd=8):
     time-MLP gradient: 1216 tiles over 256 tokens; tiny conditioning layers) are dealt one by one to the SHORTEST list (their token work is negligible, padding
     blocks are not), behind the long ones.  Every XCD then walks its list in order: physical block b = 8 * position + xcd."""
     def tiles(n, k):
-        return ((n + 255) // 256) * ((k + 127) // 128)
+        return ((n + 255) // 256) * ((k + tile_k - 1) // tile_k)
     _, m_ref = tn_token_slices(groups, 256, 768)
     lists = [[] for _ in range(n_xcd)]
     work = [0] * n_xcd                                   # token steps queued per XCD
@@ -407,8 +407,12 @@ class HipBackend:
             # one 8-wave block per CU: cut the tokens until the long tiles make ~3 rounds of 256 blocks (measured, living80: the three
             # grouped launches of a step 8.35 ms at 8 rounds / 7.9 ms at 3 / 8.6 ms at 2 -- fewer slabs to write and re-read against a
             # longer tail)
-            rounds = int(os.environ.get("DSC_TN_ROUNDS", "3"))
-            splits, _ = tn_token_slices(shapes, 256, rounds * 256)
+            # round 6: 256 x 256 tiles (four 512-register waves, half the staged bytes per MFMA) unless the form says otherwise or a
+            # group's K segments do not fall on 256-wide tiles; with half as many tiles the long ones should make ~2 rounds
+            tile_k = 256 if (self.lib.fn("dsc_get_tn_split_form")() == 2
+                             and all(not (it.get("a2") is not None and it["a"].shape[1] % 256) for it in items)) else 128
+            rounds = int(os.environ.get("DSC_TN_ROUNDS", "3" if tile_k == 128 else "2"))
+            splits, _ = tn_token_slices(shapes, 256, rounds * 256, tile_k)
             ws_off = 0
             if splits > 1:
                 for i, (n, kv, ldo) in enumerate(per_group):
@@ -417,14 +421,15 @@ class HipBackend:
                     arr[i].ws_offset = ws_off
                     ws_off += (n * kv + n) * splits
             table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
-            bmap = np.asarray(tn_block_map(shapes), dtype=np.int32).reshape(-1, 2)
-            assert int((bmap[:, 0] >= 0).sum()) == tile0s, "block map must cover every 256 x 128 tile exactly once"
+            bmap = np.asarray(tn_block_map(shapes, tile_k=tile_k), dtype=np.int32).reshape(-1, 2)
+            want_tiles = sum(((n + 255) // 256) * ((k + tile_k - 1) // tile_k) for _, n, k in shapes)
+            assert int((bmap[:, 0] >= 0).sum()) == want_tiles, "block map must cover every 256 x %d tile exactly once" % tile_k
             bmap_dev = torch.from_numpy(bmap.copy()).to(self.device)
             self.keep.append((table, items, bmap_dev))
             fn = self.lib.fn("dsc_gemm_tn_grouped_split_f32")
             tp, cnt, bp, nblk = table.data_ptr(), len(items), bmap_dev.data_ptr(), bmap.shape[0]
             return self._with_scratch(ws_off, lambda wp, wn: (fn, (tp, cnt, total, bp, nblk, splits, wp if splits > 1 else None,
-                                                                    wn if splits > 1 else 0, ws_off), "dsc_gemm_tn_grouped_split_f32"))
+                                                                    wn if splits > 1 else 0, ws_off, tile_k), "dsc_gemm_tn_grouped_split_f32"))
         # the long tiles set the duration: cut the tokens until they make ~8 rounds of 2 blocks per CU (tail < 1/8); with all
         # layers of a step in one group that is 2 slabs per gradient instead of the 32 of a per-layer launch
         splits, _ = tn_token_slices(shapes, 128, 8 * 512)

@@ -320,15 +320,20 @@ int dsc_gemm_tn_grouped_f32(const dsc_tn_group* groups_dev, int32_t count, int32
  *                  (-1, -1) = idle block.  Every tile of every group must appear exactly once.  Consecutive workgroup ids are dealt
  *                  round-robin over the 8 XCDs, so entries b, b + 8, b + 16 ... share one L2: put the tiles of one layer there.
  * total_tiles / tile0 stay the 128 x 128 numbering (used by the slab reduction when splits > 1; tile0s is unused).  Every operand must
- * satisfy m * ld * 4 < 2^31. */
+ * satisfy m * ld * 4 < 2^31.
+ * tile_k (round 6): the k width of the tiles the block map numbers -- 128 (256 x 128 tiles: the round-4 / round-5 bodies) or 256 (256 x 256
+ * tiles, tile of a group = k tile + ceil(K / 256) * n tile: the round-6 body, which needs k1 % 256 == 0 wherever k2 > 0). */
 int dsc_gemm_tn_grouped_split_f32(const dsc_tn_group* groups_dev, int32_t count, int32_t total_tiles, const int32_t* block_map_dev,
                                   int32_t blocks, int32_t splits, float* workspace, int64_t workspace_floats, int64_t workspace_needed,
-                                  dsc_stream_t stream);
+                                  int32_t tile_k, dsc_stream_t stream);
 
-/* The split-bf16 weight-gradient launch has two block bodies with IDENTICAL results: 1 = producer / consumer waves (four waves stage
- * the operands two steps ahead, four multiply: default), 0 = the round-4 body (every wave stages and multiplies).  Returns the previous
- * form (process-wide; launches already captured in a hipGraph keep theirs).  For tests that hold the two to each other bit for bit. */
+/* The split-bf16 weight-gradient launch has three block bodies with IDENTICAL results: 2 = 256 x 256 tiles, four waves of 128 x 128 with
+ * the 512-register budget (round 6, default: half the staged bytes per MFMA); 1 = 256 x 128 tiles, producer / consumer waves (round 5);
+ * 0 = the round-4 body (every wave stages and multiplies).  set returns the previous form (process-wide; launches already captured in a
+ * hipGraph keep theirs); DSC_TN_FORM in the environment gives the initial one.  The host asks get() when it builds a block map: form 2
+ * -> tile_k 256.  For tests that hold the three to each other bit for bit. */
 int dsc_set_tn_split_form(int32_t form);
+int dsc_get_tn_split_form(void);
 
 /* out[c] = sum_r x[r][c] (bias / affine gradients); workspace >= 64 * n floats. */
 int dsc_colsum_f32(const float* x, int64_t ldx, int32_t m, int32_t n, float* out, float* workspace,

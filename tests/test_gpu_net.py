@@ -141,8 +141,12 @@ def test_default_loop_is_the_captured_graph_and_draws_like_the_eager_loop(monkey
         diff.gen_samples((3, 12, 62), dev(), condition=cond, clip_denoised=True,
                          noise_fn=lambda size, dtype, device: torch.zeros(size, dtype=dtype, device=device))
         assert len(calls) == 1
+        torch.manual_seed(11)
+        yg2 = diff.gen_samples((3, 12, 62), dev(), condition=cond, clip_denoised=True)       # the graph exists now: no capture in this call
+        assert len(calls) == 2
     assert torch.equal(ye, y0)
-    assert torch.equal(yg, ye), "captured loop and eager loop differ under the same seed: %g" % float((yg - ye).abs().max())
+    assert torch.equal(yg2, ye), "captured loop and eager loop differ under the same seed: %g" % float((yg2 - ye).abs().max())
+    assert torch.equal(yg, ye), "the call that captured the graph consumed random numbers of its own: %g" % float((yg - ye).abs().max())
 
 
 def _replay(seq):

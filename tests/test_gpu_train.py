@@ -444,7 +444,7 @@ def test_weight_gradient_block_bodies_are_bit_identical(splits_scale):
     shapes = [(M, 512, 512, 0, None, True), (M, 512, 512, 512, None, False), (M, 512, 32, 0, 25, True),
               (64, 1024, 512, 0, None, True), (M, 384, 512, 0, None, False), (M, 32, 512, 0, None, True)] * splits_scale
     outs = {}
-    for form in (0, 1):
+    for form in (0, 1, 2):                      # round 4 body, producer / consumer waves (round 5), 256 x 256 tiles (round 6)
         prev = _lib.fn("dsc_set_tn_split_form")(form)
         try:
             be = HipBackend(dev())
@@ -466,10 +466,11 @@ def test_weight_gradient_block_bodies_are_bit_identical(splits_scale):
             outs[form] = [(it["out"].clone(), None if it["dbias"] is None else it["dbias"].clone()) for it in items]
         finally:
             _lib.fn("dsc_set_tn_split_form")(prev)
-    for (w0, b0), (w1, b1) in zip(outs[0], outs[1]):
-        assert bool(torch.isfinite(w1).all()) and torch.equal(w0, w1)
-        if b0 is not None:
-            assert torch.equal(b0, b1)
+    for other in (1, 2):
+        for i, ((w0, b0), (w1, b1)) in enumerate(zip(outs[0], outs[other])):
+            assert bool(torch.isfinite(w1).all()) and torch.equal(w0, w1), "form %d, group %d: dW differs from the round-4 body" % (other, i)
+            if b0 is not None:
+                assert torch.equal(b0, b1), "form %d, group %d: bias gradient differs" % (other, i)
 
 
 @pytest.mark.gpu

@@ -58,8 +58,8 @@ def test_text_training_plan_builds_on_the_host_with_short_slice_counts(tmp_path,
     chosen = []
     real = train_plan.tn_token_slices
 
-    def spy(groups, tile_n, target):
-        r = real(groups, tile_n, target)
+    def spy(groups, tile_n, target, tile_k=128):
+        r = real(groups, tile_n, target, tile_k)
         chosen.append((len(groups), r))
         return r
     monkeypatch.setattr(train_plan, "tn_token_slices", spy)
@@ -86,11 +86,17 @@ def test_block_map_puts_a_layers_tiles_on_one_xcd_and_covers_every_tile_once():
     from diffuscene_amd.train_plan import tn_block_map
     # the headline plan's launch: 59 layers of 8 tiles, 30 of 16, 3 of 4 over 20480 tokens; the packed time MLP (1216 tiles, 256 tokens)
     groups = [(20480, 512, 512)] * 59 + [(20480, 512, 1024)] * 30 + [(20480, 512, 256)] * 3 + [(256, 19456, 2048)] + [(80, 9216, 128)]
-    bm = tn_block_map(groups)
+    _check_block_map(groups, 128)
+    _check_block_map(groups, 256)             # round 6: 256 x 256 tiles
+
+
+def _check_block_map(groups, tile_k):
+    from diffuscene_amd.train_plan import tn_block_map
+    bm = tn_block_map(groups, tile_k=tile_k)
     assert len(bm) % 8 == 0
 
     def tiles(n, k):
-        return ((n + 255) // 256) * ((k + 127) // 128)
+        return ((n + 255) // 256) * ((k + tile_k - 1) // tile_k)
     seen = {}
     for b, (g, t) in enumerate(bm):
         if g < 0:

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_kernel<true, 2, 4, 5"
+pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_wave_kernel<true, 5, false>"      # (rounds 3-5: "gemm_split_kernel<true, 2, 4, 5")
 out = os.path.join(ROOT, "gpurun_out")
 
 
@@ -26,6 +26,22 @@ def counters(sub):
         if pat in k:
             res[c], name, n = v, k, cnt
     return res, name, n
+
+
+def duration_us(sub):
+    """Average duration of the matching kernel's dispatches in the same database (rocpd: kernels view)."""
+    dbs = glob.glob(os.path.join(out, "%s_%s" % (tag, sub), "**", "*.db"), recursive=True)
+    if not dbs:
+        return None
+    cur = sqlite3.connect(dbs[0]).cursor()
+    try:
+        rows = cur.execute("select name, avg(end - start) from kernels group by name").fetchall()
+    except sqlite3.Error:
+        return None
+    for k, d in rows:
+        if pat in k:
+            return d / 1e3
+    return None
 
 
 f, name, nf = counters("pmc_fetch")
@@ -53,6 +69,12 @@ if s:
     if s.get("SQ_VALU_MFMA_BUSY_CYCLES") and s.get("GRBM_GUI_ACTIVE"):
         # MFMA busy is summed over 1024 SIMDs, GRBM_GUI_ACTIVE over 8 XCDs
         rec["mfma_busy"]["busy_fraction_per_simd"] = round((s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (s["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        # effective shader clock of the launch = active cycles per XCD / its duration (kernel trace of the same pass): tells a
+        # power-throttled launch (the weight-gradient launch: ~1.86 GHz) from an issue-bound one at full clock
+        dur = duration_us("pmc_sample")
+        if dur:
+            rec["mfma_busy"]["avg_duration_us"] = round(dur, 2)
+            rec["mfma_busy"]["effective_clock_ghz"] = round(s["GRBM_GUI_ACTIVE"] / 8.0 / dur / 1e3, 3)
 path_tag = "_f32" if "gemm_kernel" in pat else ""
 path = os.path.join(out, "%s_gemm_gn_hbm_traffic%s.json" % (tag, path_tag))       # copy to profiles/rNN_gemm_gn_hbm_traffic.json to publish it
 with open(path, "w") as fh:
