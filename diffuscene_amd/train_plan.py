@@ -411,8 +411,10 @@ class HipBackend:
             # group's K segments do not fall on 256-wide tiles; with half as many tiles the long ones should make ~2 rounds
             tile_k = 256 if (self.lib.fn("dsc_get_tn_split_form")() == 2
                              and all(not (it.get("a2") is not None and it["a"].shape[1] % 256) for it in items)) else 128
+            # (living80: 506 long tiles = 1.98 rounds un-sliced -- a target of 2 whole rounds would cut them into two slices with slabs and a
+            # reduction launch for 6 missing tiles; arrange: 470 -- hence the margin of 64)
             rounds = int(os.environ.get("DSC_TN_ROUNDS", "3" if tile_k == 128 else "2"))
-            splits, _ = tn_token_slices(shapes, 256, rounds * 256, tile_k)
+            splits, _ = tn_token_slices(shapes, 256, rounds * 256 - (64 if tile_k == 256 else 0), tile_k)
             ws_off = 0
             if splits > 1:
                 for i, (n, kv, ldo) in enumerate(per_group):

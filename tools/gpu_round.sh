@@ -22,7 +22,7 @@ trace) cd /tmp && export TMPDIR=/tmp
   timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_train -o t -- python $R/bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_trace_train.log 2>&1
   cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_trace_sample -name "*.db" | head -1) > $O/${TAG}_sample_kernel_trace.txt 2>&1; python tools/rocpd_summary.py $(find $O/${TAG}_trace_train -name "*.db" | head -1) > $O/${TAG}_train_kernel_trace.txt 2>&1; head -12 $O/${TAG}_sample_kernel_trace.txt; head -25 $O/${TAG}_train_kernel_trace.txt ;;
 pmc) cd /tmp && export TMPDIR=/tmp
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -d $O/${TAG}_pmc_sample -o p -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_sample.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/${TAG}_pmc_sample -o p -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_sample.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o f -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_fetch.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o w -- python $R/bench.py --mode sample --steps 3 --warmup 1 --no-cpu-baseline --no-full-loop > $O/${TAG}_pmc_write.log 2>&1
   cd $R; python tools/rocpd_summary.py $(find $O/${TAG}_pmc_sample -name "*.db" | head -1) > $O/${TAG}_sample_pmc.txt 2>&1

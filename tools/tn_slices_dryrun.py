@@ -20,10 +20,11 @@ def old_rule(groups, tile_n, target):
     lt = sum(((n + tile_n - 1) // tile_n) * ((k + 127) // 128) for m, n, k in groups if 2 * m >= m_max)
     return max(1, min(32, -(-target // max(lt, 1))))
 log = []
-def spy(groups, tile_n, target):
-    r = real(groups, tile_n, target)
+def spy(groups, tile_n, target, tile_k=128):
+    r = real(groups, tile_n, target, tile_k)
     ms = sorted({m for m, _, _ in groups}, reverse=True)
-    log.append("   launch of %3d groups, token lengths %s: old rule %2d slices -> new %2d (m_ref %d)" % (len(groups), ms, old_rule(groups, tile_n, target), r[0], r[1]))
+    nt = sum(((n + tile_n - 1) // tile_n) * ((k + tile_k - 1) // tile_k) for m, n, k in groups if 2 * m >= r[1])
+    log.append("   launch of %3d groups, token lengths %s: old rule %2d slices -> new %2d (m_ref %d; %d long tiles of %d x %d, target %d)" % (len(groups), ms, old_rule(groups, tile_n, target), r[0], r[1], nt, tile_n, tile_k, target))
     return r
 train_plan.tn_token_slices = spy
 stats = os.path.join(tempfile.mkdtemp(), "s.txt"); open(stats, "w").write(json.dumps(W.DATASET_STATS))
