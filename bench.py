@@ -581,26 +581,31 @@ def cpu_baseline(spec, mode, sweep=False):
         per_step.sort()
         times[f.__name__] = (per_step[len(per_step) // 2], len(per_step))          # median of the timed full-batch steps
         log("cpu_baseline: %s, %d threads: median %.3f s over %d full-batch steps" % (f.__name__, best[0], times[f.__name__][0], len(per_step)))
-    # SURVEY 8d prescribes set_num_threads(os.cpu_count()): that figure too (one warm-up + one / two timed full-batch steps per kind; on
-    # the 128-thread hosts of this pool it is the SLOWER setting -- oversubscribed memory-bound ops -- which is why the headline value
-    # above uses the measured optimum)
+    # SURVEY 8d prescribes set_num_threads(os.cpu_count()): that setting too -- on a BOUNDED slice (B / 16 scenes, sampling step), next to the
+    # same slice at the fixed count.  The first full-batch attempt on a 256-thread host of this pool took 147 s per sampling step
+    # (oversubscribed memory-bound ops) and ran the default bench into its time limit; the slice keeps the leg under ~30 s.
     all_cores = None
-    if not sweep and os.environ.get("DSC_CPU_BASELINE_ALL_CORES", "1") != "0" and ncpu > fixed:
-        torch.set_num_threads(ncpu)
-        ac = {}
-        for f in legs:
-            f()
-            d = []
-            for _ in range(2 if f is sample_step else 1):
-                t1 = time.perf_counter()
-                f()
-                d.append(time.perf_counter() - t1)
-            ac[f.__name__] = min(d)
-            log("cpu_baseline: %s, ALL %d threads: %.3f s per full-batch step" % (f.__name__, ncpu, ac[f.__name__]))
-        all_cores = {"threads": ncpu, "value": round(len(ac) / sum(ac.values()), 4), "unit": "steps/s"}
-        for k, v in ac.items():
-            all_cores[k.replace("_step", "") + "_steps_per_s"] = round(1.0 / v, 4)
+    if not sweep and os.environ.get("DSC_CPU_BASELINE_ALL_CORES", "1") != "0" and ncpu > fixed and sample_step in legs:
+        sl = slice(0, max(B // 16, 1))
+
+        def slice_seconds(th, budget=30.0):
+            torch.set_num_threads(th)
+            t1 = time.perf_counter()
+            sample_step(sl)
+            warm = time.perf_counter() - t1
+            if warm > budget:
+                return warm, "warm-up call only (over the %.0f s budget)" % budget
+            t1 = time.perf_counter()
+            sample_step(sl)
+            return time.perf_counter() - t1, "second call"
+        t_fixed, _ = slice_seconds(fixed)
+        t_all, how = slice_seconds(ncpu)
         torch.set_num_threads(fixed)
+        all_cores = {"threads": ncpu, "what": "sampling step on a slice of %d scenes (B / 16), %s" % (sl.stop, how),
+                     "seconds_all_threads": round(t_all, 3), "seconds_at_%d_threads" % fixed: round(t_fixed, 3),
+                     "all_over_fixed": round(t_all / t_fixed, 2),
+                     "note": "os.cpu_count() threads is the slower setting on this host; the headline value uses the measured optimum"}
+        log("cpu_baseline: sampling slice of %d scenes: %.3f s at %d threads, %.3f s at ALL %d threads" % (sl.stop, t_fixed, fixed, t_all, ncpu))
     threads = max(threads_of.values())
     per = sum(v[0] for v in times.values()) / len(times)            # 'both': mean of the two step kinds (1:1 mix)
     model, phys = _cpu_info()

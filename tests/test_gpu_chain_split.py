@@ -152,7 +152,7 @@ def test_two_hundred_step_chain_at_b256(golden_dir, tmp_path):
             tiles = [_lib.fn("dsc_gemm_split_tile")(a, 1) for kind, a in plan.gemm_args() if kind == "gn"]
             assert len(tiles) == 56
             if arith == "split":
-                want = _lib.TILE_WAVE_GN if _lib.gemm_mode() == 2 else _lib.TILE_GN_80_W8     # (round 6: the wave-autonomous kernel by default)
+                want = _lib.TILE_WAVE_GN if _lib.load().dsc_get_split_wave() == 1 else _lib.TILE_GN_80_W8     # (round 6: the wave-autonomous kernel by default)
                 assert all(t == want for t in tiles), "B=256, N=80: every GroupNorm launch must run the benchmark's tile %d: %s" % (want, tiles)
             else:
                 assert all(t == -1 for t in tiles)
