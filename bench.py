@@ -487,6 +487,41 @@ def _cpu_info():
     return model, phys
 
 
+def spec_name(spec):
+    return next(k for k, v in CONFIGS.items() if v["title"] == spec["title"] and v["kind"] == spec["kind"])
+
+
+def cpu_slice_probe(arg, config):
+    """Child of cpu_baseline's all-cores leg: `THREADS:SCENES` -> one JSON line with the seconds of the second sampling-step call of the
+    oracle on that many scenes at that many threads (the parent enforces the time limit)."""
+    import torch
+    from oracle import ref_torch as R
+    from oracle import weights as W
+    th, n = (int(x) for x in arg.split(":"))
+    spec = dict(CONFIGS[config])
+    kw = dict(getattr(W, spec["kw"]))
+    sd = W.synth_state_dict(kw)
+    N, nc, kind = spec["objects"], spec["class_dim"], spec["kind"]
+    x = W.synth_scene_batch(n, N, nc, 32, seed=0)
+    tb = R.schedule_tables(1e-4, 0.02, 1000, "v")
+    cond = W.synth_condition(n, N, 128, 0).contiguous()
+    cross = W.synth_text_condition(n, spec.get("text_len", 32), 512, 0) if kind == "text" else None
+    if kind == "arrange":
+        cond = torch.cat([cond, torch.randn(n, N, 384)], dim=-1)
+        x = torch.cat([x[:, :, 0:3], x[:, :, 6:8]], dim=-1).contiguous()
+    t = torch.randint(0, 1000, (n,), generator=torch.Generator().manual_seed(1))
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
+    torch.set_num_threads(th)
+    out = None
+    for _ in range(2):
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            o = R.unet1d_forward(sd, kw, x, t, cond, cross)
+            R.p_sample_step(tb, x, t, o, noise, True, "v")
+        out = time.perf_counter() - t1
+    print(json.dumps({"threads": th, "scenes": n, "seconds": out}), flush=True)
+
+
 def cpu_baseline(spec, mode, sweep=False):
     """The oracle (CPU restatement of the reference path, kind 'port', pinned against the real reference by
     tests/test_oracle.py) timed on this box's host cores: FULL-batch steps of the same workload -- sampling step =
@@ -581,31 +616,31 @@ def cpu_baseline(spec, mode, sweep=False):
         per_step.sort()
         times[f.__name__] = (per_step[len(per_step) // 2], len(per_step))          # median of the timed full-batch steps
         log("cpu_baseline: %s, %d threads: median %.3f s over %d full-batch steps" % (f.__name__, best[0], times[f.__name__][0], len(per_step)))
-    # SURVEY 8d prescribes set_num_threads(os.cpu_count()): that setting too -- on a BOUNDED slice (B / 16 scenes, sampling step), next to the
-    # same slice at the fixed count.  The first full-batch attempt on a 256-thread host of this pool took 147 s per sampling step
-    # (oversubscribed memory-bound ops) and ran the default bench into its time limit; the slice keeps the leg under ~30 s.
+    # SURVEY 8d prescribes set_num_threads(os.cpu_count()): that setting too -- on a BOUNDED slice (B / 16 scenes, sampling step), in a CHILD
+    # process under a hard time limit.  On the 256-thread hosts of this pool the full-batch step took 147 s at all threads and even the
+    # 16-scene slice 134 s (0.08 s at 16 threads): oversubscribed memory-bound ops; an in-process call cannot be interrupted.
     all_cores = None
     if not sweep and os.environ.get("DSC_CPU_BASELINE_ALL_CORES", "1") != "0" and ncpu > fixed and sample_step in legs:
-        sl = slice(0, max(B // 16, 1))
-
-        def slice_seconds(th, budget=30.0):
-            torch.set_num_threads(th)
-            t1 = time.perf_counter()
-            sample_step(sl)
-            warm = time.perf_counter() - t1
-            if warm > budget:
-                return warm, "warm-up call only (over the %.0f s budget)" % budget
-            t1 = time.perf_counter()
-            sample_step(sl)
-            return time.perf_counter() - t1, "second call"
-        t_fixed, _ = slice_seconds(fixed)
-        t_all, how = slice_seconds(ncpu)
-        torch.set_num_threads(fixed)
-        all_cores = {"threads": ncpu, "what": "sampling step on a slice of %d scenes (B / 16), %s" % (sl.stop, how),
-                     "seconds_all_threads": round(t_all, 3), "seconds_at_%d_threads" % fixed: round(t_fixed, 3),
-                     "all_over_fixed": round(t_all / t_fixed, 2),
+        n_slice, limit = max(B // 16, 1), 25
+        t1 = time.perf_counter()
+        sample_step(slice(0, n_slice))
+        sample_step(slice(0, n_slice))
+        t_fixed = (time.perf_counter() - t1) / 2
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-slice-probe", "%d:%d" % (ncpu, n_slice), "--config", spec_name(spec)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit + 20,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            t_all = json.loads(line[-1])["seconds"] if line else None
+            how = "second call in a child process" if t_all is not None else "child failed: %s" % (r.stderr or "").strip()[-200:]
+        except subprocess.TimeoutExpired:
+            t_all, how = None, "child killed after %d s (model build + two calls): slower than %.0fx the %d-thread time" % (limit + 20, limit / max(t_fixed, 1e-9), fixed)
+        all_cores = {"threads": ncpu, "what": "sampling step on a slice of %d scenes (B / 16); %s" % (n_slice, how),
+                     "seconds_all_threads": None if t_all is None else round(t_all, 3), "seconds_at_%d_threads" % fixed: round(t_fixed, 3),
+                     "all_over_fixed": None if t_all is None else round(t_all / t_fixed, 2),
                      "note": "os.cpu_count() threads is the slower setting on this host; the headline value uses the measured optimum"}
-        log("cpu_baseline: sampling slice of %d scenes: %.3f s at %d threads, %.3f s at ALL %d threads" % (sl.stop, t_fixed, fixed, t_all, ncpu))
+        log("cpu_baseline: sampling slice of %d scenes: %.3f s at %d threads, %s at ALL %d threads" % (
+            n_slice, t_fixed, fixed, "%.3f s" % t_all if t_all is not None else "over the limit", ncpu))
     threads = max(threads_of.values())
     per = sum(v[0] for v in times.values()) / len(times)            # 'both': mean of the two step kinds (1:1 mix)
     model, phys = _cpu_info()
@@ -848,11 +883,15 @@ def main():
     ap.add_argument("--side-line", default=None, metavar="CONFIG[:ARITH]",
                     help="(internal) print the compact side line of one configuration and exit: the default run launches one child "
                          "process per side line, so that nothing that happens there can cost the headline line")
+    ap.add_argument("--cpu-slice-probe", default=None, metavar="THREADS:SCENES", help=argparse.SUPPRESS)
     ap.add_argument("--ddp-selftest", action="store_true",
                     help="one GPU: time the DATA-PARALLEL form of the training step (world-1 RCCL group, reducer forced on: bucket "
                          "schedule, hipGraph segments, 8 in-place all-reduces) next to the single-GPU graph step, at the config's "
                          "batch and at 1/8 of it (the strong-scaling shard)")
     args = ap.parse_args()
+    if args.cpu_slice_probe:                      # child of cpu_baseline's all-cores leg: CPU only
+        cpu_slice_probe(args.cpu_slice_probe, args.config)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))

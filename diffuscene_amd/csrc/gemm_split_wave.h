@@ -289,6 +289,28 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
         tile(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
         tile(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
     }
+    // GroupNorm form: the per-channel parameters of the epilogue's row layout (this lane's four channels of each of the two cells: gamma,
+    // beta, per-scene (scale, shift)) are requested HERE, before the last tiles of the K loop -- scattered 16-byte loads under full memory
+    // load take 1-2 k cycles, and the epilogue's statistics are too short to cover them (32 registers, free at this point)
+    f32x4 ep_ga[2], ep_be[2], ep_sc[2], ep_sh[2];
+    if constexpr (GN) {
+        const bool per_scene_e = p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX;
+        int64_t ssrow_e = scene;
+        if (p.ss_mode == DSC_SS_BY_INDEX) ssrow_e = dsc_clamp_index(p.ss_index[scene], p.ss_rows);
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ch = col0 + 64 * c2 + 4 * (lane & 15);
+            ep_ga[c2] = *reinterpret_cast<const f32x4*>(p.gamma + ch);
+            ep_be[c2] = *reinterpret_cast<const f32x4*>(p.beta + ch);
+            ep_sc[c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ep_sh[c2] = ep_sc[c2];
+            if (per_scene_e) {
+                const float* ssr = p.scale_shift + ssrow_e * p.ld_ss + ch;
+                ep_sc[c2] = *reinterpret_cast<const f32x4*>(ssr);
+                ep_sh[c2] = *reinterpret_cast<const f32x4*>(ssr + p.n);
+            }
+        }
+    }
     for (; kt < KT; kt += 2) {
         tile(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
         tile(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
@@ -386,9 +408,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
             else cells(integral_constant<int, 0>{}, integral_constant<int, DSC_ACT_NONE>{});
         }
     } else {
-        const bool per_scene = p.ss_mode == DSC_SS_PER_SCENE || p.ss_mode == DSC_SS_BY_INDEX;
-        int64_t ssrow = scene;
-        if (p.ss_mode == DSC_SS_BY_INDEX) ssrow = dsc_clamp_index(p.ss_index[scene], p.ss_rows);
 #if defined(__HIP_DEVICE_COMPILE__)
         // per-row (scale, shift): row = token (PER_TOKEN) or slot (PER_SLOT), [scale(n) | shift(n)] per row
         const __amdgpu_buffer_rsrc_t rs = row_rsrc(PERROW ? p.scale_shift + (p.ss_mode == DSC_SS_PER_TOKEN ? (int64_t)row0 * p.ld_ss : 0) : p.y, p.ld_ss,
@@ -402,13 +421,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {                  // the two GroupNorm cells of the wave: channels col0 + 64 c2 .. + 63
             const int ch = col0 + 64 * c2 + 4 * ec;       // this lane's four channels in the row layout
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + ch), be = *reinterpret_cast<const f32x4*>(p.beta + ch);
-            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
-            if (per_scene) {
-                const float* ssr = p.scale_shift + ssrow * p.ld_ss + ch;
-                sc = *reinterpret_cast<const f32x4*>(ssr);
-                sh = *reinterpret_cast<const f32x4*>(ssr + p.n);
-            }
+            const f32x4 ga = ep_ga[c2], be = ep_be[c2], sc = ep_sc[c2], sh = ep_sh[c2];      // (requested before the last K tiles)
             to_lds(c2);
             float s0 = 0.f;
 #pragma unroll
