@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
     const int M = scenes * ntok, n = 512, R = 6;
     hipStream_t s;
     CK(hipStreamCreate(&s));
+    dsc_set_split_wave(0);             // "product" below = the block-staged kernel through the library (row-major planes); the wave kernel is launched directly
     float *A[R], *Y[R], *RS[R];
     for (int r = 0; r < R; ++r) {
         A[r] = dev_random((size_t)M * K, 1.0f);
