@@ -384,7 +384,7 @@ def roofline_dominant_kernel(plan, N, config_name):
     alg = flops / (ms * 1e-3) / 1e12
     alg_mix = flops_mix / (ms_mix * 1e-3) / 1e12
     tile = _lib.fn("dsc_gemm_split_tile")(sel512[0][0], 1)             # ... and which kernel family / tile it picks
-    wave = tile in (_lib.TILE_WAVE_GN, _lib.TILE_WAVE_DENSE)
+    wave = tile in (_lib.TILE_WAVE_GN, _lib.TILE_WAVE_DENSE, _lib.TILE_WAVE_GN_64)
     kname = (("dsc_wave::gemm_split_wave_kernel<GN=true> (wave-autonomous, tile %d; " % tile if wave else "dsc_split::gemm_split_kernel<GN=true> (block-staged, tile %d; " % tile)
              + "WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; 3xbf16 split, 6 MFMA products)" % M
              if split else "dsc_gemm::gemm_kernel<GN=true> (WS-conv+GroupNorm+SiLU, M=%d,N=512,K=512; f32 MFMA)" % M)

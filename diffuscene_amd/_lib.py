@@ -17,7 +17,7 @@ ACT_NONE, ACT_GELU, ACT_SILU, ACT_LEAKY01 = 0, 1, 2, 3
 SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
 MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
 TILE_GN_80_W8, TILE_GN_80_W4, TILE_160x256, TILE_160x128_W4 = 1, 2, 5, 8      # DSC_TILE_* (dsc_gemm_split_tile)
-TILE_WAVE_GN, TILE_WAVE_DENSE = 10, 11
+TILE_WAVE_GN, TILE_WAVE_DENSE, TILE_WAVE_GN_64 = 10, 11, 12
 WS_MAX = 64
 MAX_TOKENS_PER_SCENE = 160
 

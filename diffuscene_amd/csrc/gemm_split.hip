@@ -487,7 +487,7 @@ int launch(const dsc_gemm_args* a, int ntok, hipStream_t s) {
 
 // Which split kernel takes this launch: a tile id, or -1 = none (no planes, DSC_GEMM=f32 in the environment, or a shape / alignment /
 // launch size this path does not cover: the exact-f32 MFMA kernel runs).
-enum { T_GN_32 = 0, T_GN_80_W8, T_GN_80_W4, T_GN_48, T_GN_64, T_160x256, T_256x128, T_128x128, T_160x128_W4, T_64x256, T_WAVE_GN, T_WAVE_DENSE };
+enum { T_GN_32 = 0, T_GN_80_W8, T_GN_80_W4, T_GN_48, T_GN_64, T_160x256, T_256x128, T_128x128, T_160x128_W4, T_64x256, T_WAVE_GN, T_WAVE_DENSE, T_WAVE_GN_64 };
 
 // The arithmetic of the GEMM entry points -- ONE source of truth for the library and its host code (engine, training plan, bench all
 // ask dsc_get_gemm_arithmetic): 1 = split-bf16 wherever a launch qualifies (default), 0 = exact-f32 MFMA everywhere.  Initial value
@@ -559,8 +559,15 @@ static int select_wave(const dsc_gemm_args* a, bool gn) {
         waves = (long)((a->m + 79) / 80) * (a->n / 128) * a->batch;
     }
     const long rounds = (waves + 1023) / 1024;
-    if (waves * 5 < rounds * 1024 * 4) return -1;
-    return gn ? T_WAVE_GN : T_WAVE_DENSE;
+    if (waves * 5 >= rounds * 1024 * 4) return gn ? T_WAVE_GN : T_WAVE_DENSE;
+    // half-size GroupNorm launches of 65..80-token scenes (B = 128: 512 waves of 80 x 128 would leave half the SIMDs idle): waves of 80 x 64,
+    // one GroupNorm cell each.  Measured against the four-wave block-staged tile at B = 128 (profiles/r06_wave_probe_j4.txt): 33.7 vs 38.0 us,
+    // 38.4 vs 47.4 with a residual, 34.6 vs 41.6 with per-slot (scale, shift); at two rounds (B = 256) the 80 x 128 wave tile wins (57.5 vs 67.7).
+    if (gn && a->tokens_per_scene > 64) {
+        const long w4 = 2 * waves, r4 = (w4 + 1023) / 1024;
+        if (r4 == 1 && w4 * 5 >= 1024 * 4) return T_WAVE_GN_64;
+    }
+    return -1;
 }
 
 static int select_block_tile(const dsc_gemm_args* a, bool gn);
@@ -623,7 +630,7 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
     const int tile = select_tile(a, gn);
     if (tile < 0) return DSC_SPLIT_NOT_TAKEN;
     // the planes must have the layout the chosen kernel reads (dsc_gemm_planes_layout said which before they were made)
-    const int want = (tile == T_WAVE_GN || tile == T_WAVE_DENSE) ? DSC_PLANES_FRAGMENT : DSC_PLANES_ROWMAJOR;
+    const int want = (tile == T_WAVE_GN || tile == T_WAVE_DENSE || tile == T_WAVE_GN_64) ? DSC_PLANES_FRAGMENT : DSC_PLANES_ROWMAJOR;
     if (a->w_planes_layout != want) return DSC_EINVAL;
     switch (tile) {
         case T_GN_32: return launch<true, 4, 2, 2>(a, N, s);
@@ -637,6 +644,9 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
         case T_160x128_W4: return launch<false, 2, 2, 5>(a, 80, s);
         case T_64x256: return launch<false, 2, 4, 2>(a, 32, s);
         case T_WAVE_DENSE: return dsc_wave::launch<false, 5>(a, a->w_planes, 80, s);
+        case T_WAVE_GN_64:
+            return (a->ss_mode == DSC_SS_PER_TOKEN || a->ss_mode == DSC_SS_PER_SLOT) ? dsc_wave::launch<true, 5, true, 4>(a, a->w_planes, N, s)
+                                                                                     : dsc_wave::launch<true, 5, false, 4>(a, a->w_planes, N, s);
         case T_WAVE_GN: {
             const bool perrow = a->ss_mode == DSC_SS_PER_TOKEN || a->ss_mode == DSC_SS_PER_SLOT;
             const int rb = (N + 15) / 16;
@@ -666,7 +676,7 @@ extern "C" int dsc_gemm_split_tile(const dsc_gemm_args* a, int32_t gn) {
 extern "C" int dsc_gemm_planes_layout(const dsc_gemm_args* a, int32_t gn) {
     if (!a || a->m <= 0 || a->n <= 0 || a->k1 <= 0) return DSC_EINVAL;
     const int tile = select_tile(a, gn != 0, true);
-    return tile < 0 ? -1 : (tile == T_WAVE_GN || tile == T_WAVE_DENSE) ? DSC_PLANES_FRAGMENT : DSC_PLANES_ROWMAJOR;
+    return tile < 0 ? -1 : (tile == T_WAVE_GN || tile == T_WAVE_DENSE || tile == T_WAVE_GN_64) ? DSC_PLANES_FRAGMENT : DSC_PLANES_ROWMAJOR;
 }
 
 extern "C" int dsc_split_bf16x3_f32(const dsc_split_item* items, int32_t count, dsc_stream_t stream) {

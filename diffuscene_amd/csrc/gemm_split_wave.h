@@ -37,8 +37,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 32;
 constexpr int WAVES = 4;          // per block: four scenes x one 128-channel chunk (the waves share weight lines in the CU's L1)
-constexpr int J = 8;              // 16-channel MFMA blocks per wave
-constexpr int NWF = 3 * J;        // weight fragments per K tile and wave
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -70,8 +68,13 @@ template <int RB>
 constexpr int wave_smem_bytes() { return WAVES * 2 * 3 * (16 * RB) * 64; }
 
 // GN: the fused Block epilogue (GroupNorm + (scale, shift) + SiLU); PERROW: its (scale, shift) rows are per token / per slot
-template <bool GN, int RB, bool PERROW = false>
+// J: 16-channel MFMA blocks per wave -- 8 (128 channels, two GroupNorm cells: the launches that fill the chip with 4 waves per CU) or 4 (64
+// channels, one cell: half-size launches, e.g. B = 128 scenes of 80 tokens x 512 channels = 1024 waves of 80 x 64)
+template <bool GN, int RB, bool PERROW = false, int J = 8>
 __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const dsc_gemm_args p, const uint16_t* const planes_f, const int ntok DSC_WAVE_STAMP_ARGS) {
+    static_assert(J == 8 || J == 4, "wave tile: 128 or 64 channels");
+    constexpr int NWF = 3 * J;                            // weight fragments per K tile and wave
+    constexpr int CW = 16 * J;                            // channels per wave
     constexpr int ROWS = 16 * RB, XP = ROWS * 64, STAGE = 3 * XP;
     constexpr int NWB = RB > 4 ? RB - 2 : RB > 3 ? RB - 1 : RB;   // token blocks that carry weight loads: the last ones are spared when there are enough
                                                                   // (a fragment is needed at the top of the next tile: >= 2 blocks of lead)
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int K = p.k1 + p.k2, KT = K / BK;
     const int scenes = (p.m + ntok - 1) / ntok;
-    const int sgs = (scenes + WAVES - 1) / WAVES, chunks = p.n / 128;
+    const int sgs = (scenes + WAVES - 1) / WAVES, chunks = p.n / CW;
     // XCD-aware order (block b runs on XCD b % 8): the channel chunks of a scene group sit on one XCD (its L2 serves the token rows
     // to the three other chunks)
     const int bid = blockIdx.x;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
     DSC_WAVE_STAMP_DECL
     DSC_WAVE_STAMP_KERNEL(0)
     const int z = blockIdx.y;
-    const int row0 = scene * ntok, col0 = ch * 128;
+    const int row0 = scene * ntok, col0 = ch * CW;
     const int rows_here = min(ntok, p.m - row0);
     const float* const xb1 = p.a1 + (int64_t)z * p.sa1 + (int64_t)row0 * p.lda1;
     const float* const xb2 = p.a2 ? p.a2 + (int64_t)z * p.sa2 + (int64_t)row0 * p.lda2 : xb1;
@@ -194,7 +197,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
             constexpr int i = decltype(ic)::value;
             constexpr int NR = 3;
             constexpr int W0 = i * PERW < NWF ? i * PERW : NWF, W1 = (i + 1) * PERW < NWF ? (i + 1) * PERW : NWF;
-            constexpr int S0 = NR + (W1 - W0), S1 = S0 + 22, S2 = S1 + 3, S3 = S2 + 1;
+            constexpr int VPS = J == 8 ? 2 : 4, NVS = 44 / VPS;               // VALU of the split per filler slot (24 MFMAs per block at J = 4)
+            constexpr int S0 = NR + (W1 - W0), S1 = S0 + NVS, S2 = S1 + 3, S3 = S2 + 1;
             static_assert(S3 <= NMMA, "one MFMA per filler slot");
             // split state: pair q = elements 2q, 2q + 1 of the lane's 8; op o of the 11-op chain (see split8)
             unsigned su1[4], su2[4], su3[4];
@@ -225,8 +229,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
                     constexpr int w = W0 + (k - NR);
                     wf[NXT][w / 3][w % 3] = load_w(kn1, w / 3, w % 3);
                 } else if constexpr (k < S1) {
-                    split_op(std::integral_constant<int, 2 * (k - S0)>{});
-                    split_op(std::integral_constant<int, 2 * (k - S0) + 1>{});
+                    dsc_static_for<VPS>([&](auto vc) { split_op(std::integral_constant<int, VPS * (k - S0) + decltype(vc)::value>{}); });
                 } else if constexpr (k < S2) {
                     constexpr int pl = k - S1;
                     const u32x4 v = pl == 0 ? u32x4{su1[0], su1[1], su1[2], su1[3]} : pl == 1 ? u32x4{su2[0], su2[1], su2[2], su2[3]}
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
         int64_t ssrow_e = scene;
         if (p.ss_mode == DSC_SS_BY_INDEX) ssrow_e = dsc_clamp_index(p.ss_index[scene], p.ss_rows);
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
+        for (int c2 = 0; c2 < J / 4; ++c2) {
             const int ch = col0 + 64 * c2 + 4 * (lane & 15);
             ep_ga[c2] = *reinterpret_cast<const f32x4*>(p.gamma + ch);
             ep_be[c2] = *reinterpret_cast<const f32x4*>(p.beta + ch);
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
         };
         auto cells = [&](auto modec, auto actc) {
             cell(std::integral_constant<int, 0>{}, modec, actc);
-            cell(std::integral_constant<int, 1>{}, modec, actc);
+            if constexpr (J == 8) cell(std::integral_constant<int, 1>{}, modec, actc);
         };
         using std::integral_constant;
         const int act = p.act_out;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
         // GroupNorm rows are whole scenes (m % ntok == 0): every block but the last is full
         const bool vlast = (RB - 1) * 16 + l15 < rows_here;
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {                  // the two GroupNorm cells of the wave: channels col0 + 64 c2 .. + 63
+        for (int c2 = 0; c2 < J / 4; ++c2) {              // the GroupNorm cells of the wave (two at J = 8): channels col0 + 64 c2 .. + 63
             const int ch = col0 + 64 * c2 + 4 * ec;       // this lane's four channels in the row layout
             const f32x4 ga = ep_ga[c2], be = ep_be[c2], sc = ep_sc[c2], sh = ep_sh[c2];      // (requested before the last K tiles)
             to_lds(c2);
@@ -490,12 +493,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
     DSC_WAVE_STAMP_END
 }
 
-template <bool GN, int RB, bool PERROW = false>
+template <bool GN, int RB, bool PERROW = false, int J = 8>
 int launch(const dsc_gemm_args* a, const uint16_t* planes_f, int ntok, hipStream_t s) {
     const int scenes = (a->m + ntok - 1) / ntok;
-    const unsigned grid = (unsigned)(((scenes + WAVES - 1) / WAVES) * (a->n / 128));
+    const unsigned grid = (unsigned)(((scenes + WAVES - 1) / WAVES) * (a->n / (16 * J)));
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((gemm_split_wave_kernel<GN, RB, PERROW>), dim3(grid, (unsigned)a->batch), dim3(64 * WAVES), 0, s, *a, planes_f, ntok DSC_WAVE_STAMP_PASS);
+    hipLaunchKernelGGL((gemm_split_wave_kernel<GN, RB, PERROW, J>), dim3(grid, (unsigned)a->batch), dim3(64 * WAVES), 0, s, *a, planes_f, ntok DSC_WAVE_STAMP_PASS);
     DSC_LAUNCH_CHECK();
     return 0;
 }

@@ -130,6 +130,7 @@ int dsc_gemm_arithmetic(const dsc_gemm_args* args, int32_t gn);
 #define DSC_TILE_64x256      9
 #define DSC_TILE_WAVE_GN     10  /* wave-autonomous kernel: one scene of 17..80 tokens x 128 channels per wave, 4 waves per block */
 #define DSC_TILE_WAVE_DENSE  11  /* the same on dense rows (groups of 80) */
+#define DSC_TILE_WAVE_GN_64  12  /* half-size GroupNorm launches: one scene of 65..80 tokens x 64 channels per wave */
 int dsc_gemm_split_tile(const dsc_gemm_args* args, int32_t gn);
 
 /* The planes layout the launch wants: DSC_PLANES_ROWMAJOR / DSC_PLANES_FRAGMENT, or -1 when it stays on the exact-f32 kernel whatever

@@ -48,7 +48,7 @@ def test_fragment_major_planes_hold_the_same_values():
     assert tuple(fragt.shape) == (3, 160, 384)
 
 
-@pytest.mark.parametrize("N,scenes", [(80, 256), (70, 256), (48, 256), (33, 256), (21, 256), (80, 512), (80, 210)])
+@pytest.mark.parametrize("N,scenes", [(80, 256), (70, 256), (48, 256), (33, 256), (21, 256), (80, 512), (80, 210), (80, 128), (70, 120)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_groupnorm_forms_agree_bit_for_bit(N, scenes, mode):
     """Block.forward as one launch: no / per-token / per-scene / per-slot / per-timestep (scale, shift); residual; saved pre-activation;
@@ -78,6 +78,8 @@ def test_groupnorm_forms_agree_bit_for_bit(N, scenes, mode):
         waves = scenes * n // 128
         if waves * 5 >= -(-waves // 1024) * 1024 * 4:
             assert tw == _lib.TILE_WAVE_GN and tb != tw, (tb, tw)
+        elif N > 64 and 2 * waves <= 1024 and 2 * waves * 5 >= 1024 * 4:
+            assert tw == _lib.TILE_WAVE_GN_64 and tb != tw, (tb, tw)          # half-size launches: waves of 80 x 64
         assert torch.isfinite(yw).all()
         assert torch.equal(yb, yw), "GroupNorm GEMM N=%d mode=%d K=%d+%d: wave kernel != block kernel" % (N, mode, k1, k2)
         if pre:

@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     const int gn = argc > 1 ? atoi(argv[1]) : 1, res = argc > 2 ? atoi(argv[2]) : 0;
     const int K = argc > 3 ? atoi(argv[3]) : 512, reps = argc > 4 ? atoi(argv[4]) : 300;
     const int scenes = argc > 5 ? atoi(argv[5]) : 256, ntok = argc > 6 ? atoi(argv[6]) : 80;
-    const int ssmode = argc > 7 ? atoi(argv[7]) : DSC_SS_PER_SCENE, pre = argc > 8 ? atoi(argv[8]) : 0;
+    const int ssmode = argc > 7 ? atoi(argv[7]) : DSC_SS_PER_SCENE, pre = argc > 8 ? atoi(argv[8]) : 0, jb = argc > 9 ? atoi(argv[9]) : 8;
     const int M = scenes * ntok, n = 512, R = 6;
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -127,6 +127,8 @@ int main(int argc, char** argv) {
     auto probe = [&](const dsc_gemm_args& a) {
         const int rb = (ntok + 15) / 16;
         const bool pr = ssmode == DSC_SS_PER_TOKEN || ssmode == DSC_SS_PER_SLOT;
+        if (gn && jb == 4 && rb == 5) return pr ? dsc_wave::launch<true, 5, true, 4>(&a, planes_f, ntok, s) : dsc_wave::launch<true, 5, false, 4>(&a, planes_f, ntok, s);
+        if (!gn && jb == 4) return dsc_wave::launch<false, 5, false, 4>(&a, planes_f, 80, s);
         if (gn && pr) return rb == 5 ? dsc_wave::launch<true, 5, true>(&a, planes_f, ntok, s) : dsc_wave::launch<true, 2, true>(&a, planes_f, ntok, s);
         if (gn) return rb == 5 ? dsc_wave::launch<true, 5>(&a, planes_f, ntok, s) : rb == 4 ? dsc_wave::launch<true, 4>(&a, planes_f, ntok, s)
                      : rb == 3 ? dsc_wave::launch<true, 3>(&a, planes_f, ntok, s) : dsc_wave::launch<true, 2>(&a, planes_f, ntok, s);
