@@ -264,22 +264,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
     for (int u = 0; u < RB; ++u) load_tok(0, u, integral_constant<int, 0>{});
 #pragma unroll
     for (int w = 0; w < NWF; ++w) wf[0][w / 3][w % 3] = load_w(0, w / 3, w % 3);
-    {   // the rows of tile 1 are requested before anything waits for tile 0 (one memory round trip in the prologue, not two): they land
-        // in the registers the split of tile 0 frees
-        f32x4 ld0[RB][2];
+    // Every CU's waves are in this prologue at once and the memory system serves the burst at ~11 B per cycle and CU: what is requested
+    // before the first MFMA IS the prologue.  So the rows of tile 1 are requested block by block BEHIND the split of tile 0 (8.4 k cycles;
+    // requesting them up front, "one round trip instead of two", measured 10 k: profiles/r06_wave_probe_4.txt vs _5.txt)
 #pragma unroll
-        for (int u = 0; u < RB; ++u) { ld0[u][0] = ld[u][0]; ld0[u][1] = ld[u][1]; }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) load_tok(1, u, integral_constant<int, 0>{});
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            bf16x8 a, b, c;
-            split8(ld0[u][0], ld0[u][1], a, b, c);
-            char* d0 = wl + u * 1024 + ildso;
-            *reinterpret_cast<bf16x8*>(d0) = a;
-            *reinterpret_cast<bf16x8*>(d0 + XP) = b;
-            *reinterpret_cast<bf16x8*>(d0 + 2 * XP) = c;
-        }
+    for (int u = 0; u < RB; ++u) {
+        bf16x8 a, b, c;
+        split8(ld[u][0], ld[u][1], a, b, c);
+        char* d0 = wl + u * 1024 + ildso;
+        *reinterpret_cast<bf16x8*>(d0) = a;
+        *reinterpret_cast<bf16x8*>(d0 + XP) = b;
+        *reinterpret_cast<bf16x8*>(d0 + 2 * XP) = c;
+        load_tok(1, u, integral_constant<int, 0>{});
     }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const bf16x8*>(wl + pl * XP + xoff);
