@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_wave_kernel<true, 5, false>"      # (rounds 3-5: "gemm_split_kernel<true, 2, 4, 5")
+pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_wave_kernel<true, 5, false, 8>"      # (rounds 3-5: "gemm_split_kernel<true, 2, 4, 5")
 out = os.path.join(ROOT, "gpurun_out")
 
 
