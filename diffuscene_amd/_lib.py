@@ -50,6 +50,9 @@ class GemmArgs(C.Structure):
         ("actgrad_x", C.c_void_p), ("ld_actgrad", C.c_int64),
         ("ss_rows", C.c_int32),
         ("w_planes_layout", C.c_int32),
+        ("gnb_z", C.c_void_p), ("ld_gnb_z", C.c_int64),
+        ("gnb_dgamma", C.c_void_p), ("gnb_dbeta", C.c_void_p), ("gnb_dbias", C.c_void_p), ("gnb_pstride", C.c_int64),
+        ("gnb_dss", C.c_void_p), ("ld_gnb_dss", C.c_int64),
     ]
 
 

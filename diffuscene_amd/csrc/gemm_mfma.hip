@@ -77,7 +77,7 @@ extern "C" int dsc_gemm_f32(const dsc_gemm_args* a, dsc_stream_t stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = dsc_gemm_try_split(a, false, s);                // pre-split weight planes supplied: f32-accurate product on the bf16 pipe
     if (rc != DSC_SPLIT_NOT_TAKEN) return rc;
-    if (a->preact || a->actgrad_x) return DSC_EINVAL;    // the training-step epilogues exist on the split kernel only: fail, never ignore
+    if (a->preact || a->actgrad_x || a->gnb_z) return DSC_EINVAL;    // the training-step epilogues exist on the split kernels only: fail, never ignore
     const bool wide = (a->n % 256) == 0;
     struct Cand { int bm, bn, id; };
     // ties go to the earlier candidate: 160 x 128 (2 blocks per CU) measured 1 % ahead of 160 x 256 at M = 20480

@@ -549,6 +549,19 @@ static int select_wave(const dsc_gemm_args* a, bool gn) {
     const int64_t ld_max = a->lda1 > a->lda2 ? a->lda1 : a->lda2;
     if (ld_max * 4 * 96 >= 0x7fffffffLL) return -1;                                     // 32-bit byte offsets inside a wave's rows
     long waves;
+    if (a->gnb_z) {
+        // GroupNorm-backward epilogue: dense product over whole scenes of 65..80 tokens, the epilogue's operands in whole 16-byte columns
+        const int N = a->tokens_per_scene;
+        if (gn || a->batch != 1 || N <= 64 || N > 80 || (a->m % N) || a->bias || a->residual || a->preact || a->actgrad_x || a->act_out != DSC_ACT_NONE) return -1;
+        if (!a->gamma || !a->beta || !a->gnb_dgamma || !a->gnb_dbeta || !a->gnb_dbias || (a->ss_mode != DSC_SS_NONE && a->ss_mode != DSC_SS_PER_SCENE)) return -1;
+        if (!dsc_aligned16(a->gnb_z) || (a->ld_gnb_z & 3) || a->ld_gnb_z < a->n || !dsc_aligned16(a->gamma) || !dsc_aligned16(a->beta)) return -1;
+        if (!dsc_aligned16(a->gnb_dgamma) || !dsc_aligned16(a->gnb_dbeta) || !dsc_aligned16(a->gnb_dbias) || (a->gnb_pstride & 3)) return -1;
+        if (a->ss_mode == DSC_SS_PER_SCENE && (!a->scale_shift || !dsc_aligned16(a->scale_shift) || (a->ld_ss & 3))) return -1;
+        if (a->gnb_dss && (!dsc_aligned16(a->gnb_dss) || (a->ld_gnb_dss & 3))) return -1;
+        waves = (long)(a->m / N) * (a->n / 128);
+        const long r = (waves + 1023) / 1024;
+        return waves * 5 >= r * 1024 * 4 ? T_WAVE_DENSE : -1;
+    }
     if (gn) {
         const int N = a->tokens_per_scene;
         if (N <= 16 || N > 80) return -1;
@@ -580,6 +593,7 @@ static int select_tile(const dsc_gemm_args* a, bool gn, bool assume_planes = fal
 }
 
 static int select_block_tile(const dsc_gemm_args* a, bool gn) {
+    if (a->gnb_z) return -1;                             // (the GroupNorm-backward epilogue exists on the wave-autonomous kernel only)
     const int K = a->k1 + a->k2;
     // grouped launches: the weights of the problems must be the row blocks of one stacked matrix (planes [3][batch n][K])
     if (a->batch != 1 && (gn || a->sw != (int64_t)a->n * K || a->ldw != K || (a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return -1;
@@ -643,7 +657,9 @@ int dsc_gemm_try_split(const dsc_gemm_args* a, bool gn, hipStream_t s) {
         case T_128x128: return launch<false, 4, 2, 2>(a, 32, s);
         case T_160x128_W4: return launch<false, 2, 2, 5>(a, 80, s);
         case T_64x256: return launch<false, 2, 4, 2>(a, 32, s);
-        case T_WAVE_DENSE: return dsc_wave::launch<false, 5>(a, a->w_planes, 80, s);
+        case T_WAVE_DENSE:
+            if (a->gnb_z) return dsc_wave::launch<false, 5, false, 8, true>(a, a->w_planes, N, s);       // GroupNorm-backward epilogue: rows = scenes
+            return dsc_wave::launch<false, 5>(a, a->w_planes, 80, s);
         case T_WAVE_GN_64:
             return (a->ss_mode == DSC_SS_PER_TOKEN || a->ss_mode == DSC_SS_PER_SLOT) ? dsc_wave::launch<true, 5, true, 4>(a, a->w_planes, N, s)
                                                                                      : dsc_wave::launch<true, 5, false, 4>(a, a->w_planes, N, s);

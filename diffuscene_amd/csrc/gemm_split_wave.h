@@ -70,9 +70,12 @@ constexpr int wave_smem_bytes() { return WAVES * 2 * 3 * (16 * RB) * 64; }
 // GN: the fused Block epilogue (GroupNorm + (scale, shift) + SiLU); PERROW: its (scale, shift) rows are per token / per slot
 // J: 16-channel MFMA blocks per wave -- 8 (128 channels, two GroupNorm cells: the launches that fill the chip with 4 waves per CU) or 4 (64
 // channels, one cell: half-size launches, e.g. B = 128 scenes of 80 tokens x 512 channels = 1024 waves of 80 x 64)
-template <bool GN, int RB, bool PERROW = false, int J = 8>
+// GB (dense form only): GroupNorm-backward epilogue -- the product is the gradient w.r.t. a fused Block's output, the kernel writes the gradient w.r.t.
+// its pre-norm activation (dsc_gemm_args.gnb_*)
+template <bool GN, int RB, bool PERROW = false, int J = 8, bool GB = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const dsc_gemm_args p, const uint16_t* const planes_f, const int ntok DSC_WAVE_STAMP_ARGS) {
     static_assert(J == 8 || J == 4, "wave tile: 128 or 64 channels");
+    static_assert(!GB || (!GN && J == 8), "the GroupNorm-backward epilogue rides on the dense 80 x 128 form");
     constexpr int NWF = 3 * J;                            // weight fragments per K tile and wave
     constexpr int CW = 16 * J;                            // channels per wave
     constexpr int ROWS = 16 * RB, XP = ROWS * 64, STAGE = 3 * XP;
@@ -352,7 +355,100 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
     // activation-gradient operand: one latency per half cell instead of one per row group), then LDS reads, arithmetic, stores.
     constexpr int NQ = ROWS / 4, QH = NQ % 10 == 0 ? 10 : NQ % 8 == 0 ? 8 : NQ % 6 == 0 ? 6 : 4;
     static_assert(NQ % QH == 0, "row groups per pass");
-    if constexpr (!GN) {
+    if constexpr (GB) {
+        // GroupNorm-backward epilogue (the arithmetic of train.hip: gn_silu_bwd_reg_kernel, per cell of one scene x 64 channels, here in the row layout: a lane holds
+        // rows 4 q + er, four channels): dh = the product (from the LDS image), z = the Block's saved pre-norm activation (whole 256-byte row pieces).
+        //   mu, rs      statistics of z over the cell (two wave sums)
+        //   u = (ga xh + be) (1 + scale) + shift,  du = dh silu'(u),  dgh = du (1 + scale),  dxh = dgh ga
+        //   dz = rs (dxh - mean(dxh) - xh mean(dxh xh))                                      (two more wave sums)
+        //   per-scene column sums: dgamma += dgh xh, dbeta += dgh, dbias += dz, d scale += du gh, d shift += du
+        const float inv_cnt = 1.f / (float)(ntok * 64);
+        const bool per_scene = p.ss_mode == DSC_SS_PER_SCENE && p.scale_shift;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __amdgpu_buffer_rsrc_t rz = row_rsrc(p.gnb_z + (int64_t)row0 * p.ld_gnb_z, p.ld_gnb_z, rows_here, p.n);
+#else
+        const int rz = 0;
+#endif
+        dsc_static_for<2>([&](auto c2c) {
+            constexpr int c2 = decltype(c2c)::value;
+            const int ch = col0 + 64 * c2 + 4 * ec, cc = ch * 4;
+            const int vy = er * (int)p.ldy * 4 + cc, vz = er * (int)p.ld_gnb_z * 4 + cc;
+            f32x4 zv[NQ], dv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) zv[q] = ld4(rz, vz, 4 * q * (int)p.ld_gnb_z * 4);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + ch), be = *reinterpret_cast<const f32x4*>(p.beta + ch);
+            f32x4 s1 = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (per_scene) {
+                const float* ssr = p.scale_shift + (int64_t)scene * p.ld_ss + ch;
+                s1 = *reinterpret_cast<const f32x4*>(ssr) + 1.f;
+                sh = *reinterpret_cast<const f32x4*>(ssr + p.n);
+            }
+            to_lds(c2);
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                dv[q] = *reinterpret_cast<const f32x4*>(wl + (4 * q + er) * ERS + ec * 16);
+                const bool ok = 4 * q + er < rows_here;              // (rows past the scene: z read zeros, the product is padding -- neither may count)
+                if (!ok) dv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s += ok ? (zv[q][0] + zv[q][1]) + (zv[q][2] + zv[q][3]) : 0.f;
+            }
+            const float mu = wave_sum_dpp(s) * inv_cnt;
+            s = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const bool ok = 4 * q + er < rows_here;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = ok ? zv[q][e] - mu : 0.f; s = fmaf(d, d, s); }
+            }
+            const float rs = 1.0f / sqrtf(wave_sum_dpp(s) * inv_cnt + p.eps);
+            float S1 = 0.f, S2 = 0.f;
+            f32x4 Gg = {0.f, 0.f, 0.f, 0.f}, Gb = Gg, Gsc = Gg, Gsh = Gg, Gz = Gg;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (zv[q][e] - mu) * rs;
+                    const float gh = ga[e] * xh + be[e];
+                    const float u = gh * s1[e] + sh[e];
+                    const float sig = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+                    const float du = dv[q][e] * (sig * (1.0f + u * (1.0f - sig)));
+                    const float dgh = du * s1[e];
+                    const float dxh = dgh * ga[e];
+                    S1 += dxh; S2 += dxh * xh;
+                    Gg[e] += dgh * xh; Gb[e] += dgh; Gsc[e] += du * gh; Gsh[e] += du;
+                    zv[q][e] = xh;
+                    dv[q][e] = dxh;
+                }
+            }
+            const float m1 = wave_sum_dpp(S1) * inv_cnt, m2 = wave_sum_dpp(S2) * inv_cnt;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const bool ok = 4 * q + er < rows_here;
+                f32x4 dzv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dzv[e] = rs * (dv[q][e] - m1 - zv[q][e] * m2); Gz[e] += ok ? dzv[e] : 0.f; }
+                st4(dzv, ry, vy, 4 * q * (int)p.ldy * 4);
+            }
+            // column sums over the scene's rows: in-lane over q (above), then over the four row lanes er that share a column quad
+            auto fold = [&](f32x4 v) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] += __shfl_xor(v[e], 16, 64); v[e] += __shfl_xor(v[e], 32, 64); }
+                return v;
+            };
+            Gg = fold(Gg); Gb = fold(Gb); Gz = fold(Gz);
+            if (per_scene && p.gnb_dss) { Gsc = fold(Gsc); Gsh = fold(Gsh); }
+            if (lane < 16) {
+                const int64_t o = (int64_t)scene * p.gnb_pstride + ch;
+                *reinterpret_cast<f32x4*>(p.gnb_dgamma + o) = Gg;
+                *reinterpret_cast<f32x4*>(p.gnb_dbeta + o) = Gb;
+                *reinterpret_cast<f32x4*>(p.gnb_dbias + o) = Gz;
+                if (per_scene && p.gnb_dss) {
+                    *reinterpret_cast<f32x4*>(p.gnb_dss + (int64_t)scene * p.ld_gnb_dss + ch) = Gsc;
+                    *reinterpret_cast<f32x4*>(p.gnb_dss + (int64_t)scene * p.ld_gnb_dss + p.n + ch) = Gsh;
+                }
+            }
+        });
+    } else if constexpr (!GN) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const __amdgpu_buffer_rsrc_t rg = row_rsrc(p.actgrad_x ? p.actgrad_x + (int64_t)z * p.sy + (int64_t)row0 * p.ld_actgrad : p.y, p.ld_actgrad, p.actgrad_x ? rows_here : 0, p.n);
 #else
@@ -489,12 +585,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void gemm_split_wave_kernel(const ds
     DSC_WAVE_STAMP_END
 }
 
-template <bool GN, int RB, bool PERROW = false, int J = 8>
+template <bool GN, int RB, bool PERROW = false, int J = 8, bool GB = false>
 int launch(const dsc_gemm_args* a, const uint16_t* planes_f, int ntok, hipStream_t s) {
     const int scenes = (a->m + ntok - 1) / ntok;
     const unsigned grid = (unsigned)(((scenes + WAVES - 1) / WAVES) * (a->n / (16 * J)));
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((gemm_split_wave_kernel<GN, RB, PERROW, J>), dim3(grid, (unsigned)a->batch), dim3(64 * WAVES), 0, s, *a, planes_f, ntok DSC_WAVE_STAMP_PASS);
+    hipLaunchKernelGGL((gemm_split_wave_kernel<GN, RB, PERROW, J, GB>), dim3(grid, (unsigned)a->batch), dim3(64 * WAVES), 0, s, *a, planes_f, ntok DSC_WAVE_STAMP_PASS);
     DSC_LAUNCH_CHECK();
     return 0;
 }

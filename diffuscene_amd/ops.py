@@ -41,7 +41,7 @@ def as2d(w):
 
 def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
                    gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None,
-                   ss_index=None, w_planes=None, actgrad_x=None):
+                   ss_index=None, w_planes=None, actgrad_x=None, gnb=None):
     """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
     pointers only; the caller keeps the tensors alive.  ``w_planes``: the weight pre-split into bf16 planes (split_planes):
     the product runs on the bf16 matrix cores with f32 accuracy where the kernel supports the shape."""
@@ -78,6 +78,14 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         g.actgrad_x, g.ld_actgrad = _mat(actgrad_x, "actgrad_x")
         if tuple(actgrad_x.shape) != (g.m, g.n):
             raise RuntimeError("actgrad_x shape %s != (%d, %d)" % (tuple(actgrad_x.shape), g.m, g.n))
+    if gnb is not None:
+        # GroupNorm-backward epilogue (include/diffuscene_hip.h, gnb_*): dict(z=, dgamma=, dbeta=, dbias=, pstride=, dss=None); gamma / beta / eps /
+        # tokens_per_scene / scale_shift / ss_mode above describe the Block whose output gradient this product is
+        g.gnb_z, g.ld_gnb_z = _mat(gnb["z"], "gnb z")
+        g.gnb_dgamma, g.gnb_dbeta, g.gnb_dbias = gnb["dgamma"], gnb["dbeta"], gnb["dbias"]
+        g.gnb_pstride = gnb["pstride"]
+        if gnb.get("dss") is not None:
+            g.gnb_dss, g.ld_gnb_dss = _mat(gnb["dss"], "gnb dss")
     if ss_index is not None:
         if scale_shift is None:
             raise RuntimeError("ss_index (DSC_SS_BY_INDEX) needs the scale_shift table it indexes")
@@ -88,7 +96,7 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
         if (w_planes.dtype != torch.int16 or w_planes.dim() != 3 or w_planes.shape[0] != 3 or w_planes.shape[1] % g.n
                 or w_planes.shape[2] != g.k1 + g.k2 or not w_planes.is_contiguous()):
             raise RuntimeError("w_planes must be a contiguous int16 tensor of shape (3, %d, %d)" % (g.n, g.k1 + g.k2))
-        attach_planes(g, w_planes, gn=gamma is not None)
+        attach_planes(g, w_planes, gn=gamma is not None and gnb is None)       # (gnb: a dense product that borrows the Block's gamma / beta)
     return g
 
 

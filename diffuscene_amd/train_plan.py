@@ -38,13 +38,15 @@ def _as2d(w):
 
 class H:
     """Activation handle: forward tensor + (build-time) gradient tensor."""
-    __slots__ = ("t", "g", "ng", "act_of", "g_pre", "uses")
+    __slots__ = ("t", "g", "ng", "act_of", "g_pre", "uses", "gn_of", "gn_part")
 
     def __init__(self, t, needs_grad=True):
         self.t, self.g, self.ng = t, None, needs_grad
         self.uses = 0             # consumers counted while the forward list is built (TrainPlan._use)
         self.act_of = None        # (pre-activation tensor, kind) when this handle is act(pre-activation) with ONE consumer
         self.g_pre = None         # gradient w.r.t. the pre-activation, written directly by the consumer's input-gradient GEMM
+        self.gn_of = None         # dict(z, gamma, beta, ss, ss_mode, dss, n_tok) when this handle is the output of a fused Block (conv_gn) with ONE consumer
+        self.gn_part = None       # [scenes][3 D] partial sums written by the consumer's input-gradient GEMM together with g_pre
 
 
 # ======================================================================================================================
@@ -248,6 +250,36 @@ class HipBackend:
         else:
             self.f32_reads.add(w.untyped_storage().data_ptr())
         return self._call("dsc_gemm_f32", C.byref(g), keep=(g, a, w, out, bias, a2, residual, pl))
+
+    def _gnbwd_args(self, dy, wt, dz, gn, part):
+        from . import ops
+        Cc = dz.shape[1]
+        # row layout [dbias | dgamma | dbeta] (the order of the parameters in G), as gn_bwd; part None: the question only (any aligned addresses)
+        pp, ps = (part.data_ptr(), part.stride(0)) if part is not None else (0x100000, 3 * Cc)
+        g = ops.make_gemm_args(dy, wt, dz, gamma=gn["gamma"], beta=gn["beta"], eps=1e-5, tokens_per_scene=gn["n_tok"],
+                               scale_shift=gn["ss"], ss_mode=gn["ss_mode"] if gn["ss"] is not None else SS_NONE,
+                               gnb=dict(z=gn["z"], dgamma=pp + 4 * Cc, dbeta=pp + 8 * Cc, dbias=pp, pstride=ps, dss=gn["dss"]))
+        return g
+
+    def fuse_gnbwd_ok(self, dy, wt, like, gn):
+        """Can the input-gradient GEMM dh = dy . W carry the GroupNorm backward of the Block that produced h in its epilogue (round 6: the
+        wave-autonomous kernel's row-layout epilogue; include/diffuscene_hip.h, gnb_*)?  The library decides, on a struct of the launch's
+        shape (``like``: a tensor of the output's shape and alignment -- nothing is allocated for the question)."""
+        from . import ops
+        if not self.split or os.environ.get("DSC_FUSE_GNBWD", "1") == "0" or gn["ss_mode"] not in (SS_NONE, SS_PER_SCENE):
+            return False
+        g = self._gnbwd_args(dy, wt, like, gn, None)
+        return ops.planes_layout(g) == ops.PLANES_FRAGMENT and self.planes_of(wt, dy.shape[0], ops.PLANES_FRAGMENT) is not None
+
+    def gemm_gnbwd(self, dy, wt, dz, gn, part):
+        from . import ops
+        g = self._gnbwd_args(dy, wt, dz, gn, part)
+        lay = ops.planes_layout(g)
+        pl = self.planes_of(wt, dy.shape[0], lay) if lay >= 0 else None
+        if pl is None:
+            raise RuntimeError("HipBackend.gemm_gnbwd: planned for a launch the wave-autonomous kernel does not take")
+        ops.attach_planes(g, pl, layout=lay)
+        return self._call("dsc_gemm_f32", C.byref(g), keep=(g, dy, wt, dz, gn["z"], gn["gamma"], gn["beta"], gn["ss"], gn["dss"], part, pl))
 
     def gemm_long_k(self, a, w, out, residual=None):
         """out = a @ w^T (+ residual) for a LONG reduction (K > 4096) with few output tiles: one dsc_gemm_splitk_f32 launch with the most
@@ -749,6 +781,16 @@ class TrainPlan:
                 a.g_pre = self.new(*a.t.shape)
                 self.emit(self.be.gemm(dy, wt, a.g_pre, act_out=kind, actgrad_x=u))
                 return
+            if (a.gn_of is not None and a.uses == 1 and a.g is None and a.g_pre is None and hasattr(self.be, "fuse_gnbwd_ok")):
+                # a = Block(...) output and this GEMM is its ONLY consumer: the gradient w.r.t. the Block's pre-norm activation comes straight
+                # out of this GEMM's epilogue (round 6) -- the gn_silu_bwd launch of that Block (read z, read d a, write d z) disappears
+                gn = a.gn_of
+                if self.be.fuse_gnbwd_ok(dy, wt, a.t, gn):
+                    dz = self.new(*a.t.shape)
+                    part = self.new(a.t.shape[0] // gn["n_tok"], 3 * a.t.shape[1])
+                    a.g_pre, a.gn_part = dz, part
+                    self.emit(self.be.gemm_gnbwd(dy, wt, dz, gn, part))
+                    return
             dst, acc = self.g_target(a)
             self._gemm_acc(dy, wt, dst, acc)
             return
@@ -953,19 +995,28 @@ class TrainPlan:
         self.emit(self.be.gemm_gn(a.t, w_std, y.t, conv.bias, norm.weight, norm.bias, self.N, a2.t if a2 is not None else None,
                                   ss, ss_mode, residual.t if residual is not None else None, z))
 
+        if residual is None:
+            # candidate for the fused backward: if this output ends up with ONE consumer whose input-gradient GEMM runs the wave-autonomous kernel,
+            # that GEMM's epilogue does this Block's GroupNorm backward (g_gemm); per-scene or no (scale, shift) only
+            y.gn_of = dict(z=z, gamma=norm.weight, beta=norm.bias, ss=ss, ss_mode=ss_mode if ss is not None else SS_NONE,
+                           dss=dss if (ss is not None and ss_mode == SS_PER_SCENE) else None, n_tok=self.N)
+
         def bw():
             dy = y.g
-            if dy is None:
+            if dy is None and y.g_pre is None:
                 return
             scenes = rows // self.N
-            dz = self.new(rows, D)
-            part = self.new(scenes, 3 * D)
             slot_tmp = None
-            dss_arg = dss
-            if ss is not None and ss_mode == SS_PER_SLOT:
-                slot_tmp = self.new(rows, 2 * D)          # per-token, reduced over the batch below
-                dss_arg = slot_tmp
-            self.emit(self.be.gn_bwd(z, dy, norm.weight, norm.bias, ss, ss_mode, dz, part, dss_arg, scenes, self.N))
+            if y.g_pre is not None:                        # d z and the partial sums were written by the consumer's input-gradient GEMM
+                dz, part = y.g_pre, y.gn_part
+            else:
+                dz = self.new(rows, D)
+                part = self.new(scenes, 3 * D)
+                dss_arg = dss
+                if ss is not None and ss_mode == SS_PER_SLOT:
+                    slot_tmp = self.new(rows, 2 * D)          # per-token, reduced over the batch below
+                    dss_arg = slot_tmp
+                self.emit(self.be.gn_bwd(z, dy, norm.weight, norm.bias, ss, ss_mode, dz, part, dss_arg, scenes, self.N))
             o_b, o_g, o_be = (self.flat.grad_range(p)[0] for p in (conv.bias, norm.weight, norm.bias))
             if o_g == o_b + D and o_be == o_g + D:
                 self.colsum_later(part, self.flat.G[o_b:o_b + 3 * D], params=(conv.bias, norm.weight, norm.bias))

@@ -102,6 +102,15 @@ typedef struct dsc_gemm_args {
      * decision -- ask dsc_gemm_planes_layout() BEFORE making the planes; a launch whose planes have the other layout fails with
      * DSC_EINVAL (it is never computed on the wrong bytes, never silently sent to another kernel). */
     int32_t w_planes_layout;
+    /* ---- GroupNorm-backward epilogue of dsc_gemm_f32 (round 6; wave-autonomous kernel only: DSC_TILE_WAVE_DENSE with rows = whole scenes of 65..80 tokens) ----
+     * The product P = [A1|A2].W^T is the gradient w.r.t. the OUTPUT of a fused Block (dsc_gemm_gn_silu_f32) whose saved pre-norm activation is gnb_z; y receives
+     * the gradient w.r.t. that pre-norm activation -- what dsc_gn_silu_bwd_f32 computes from (gnb_z, P) -- and the per-scene partial sums go to gnb_dgamma /
+     * gnb_dbeta / gnb_dbias (row b at + b * gnb_pstride) and, with DSC_SS_PER_SCENE, the per-scene d(scale, shift) to gnb_dss ([scenes][2 n] rows of ld_gnb_dss).
+     * gamma, beta, eps, tokens_per_scene, scale_shift, ld_ss, ss_mode describe that Block (ss_mode DSC_SS_NONE or DSC_SS_PER_SCENE); bias, act_out, residual,
+     * preact and actgrad_x must be unset.  A launch that sets gnb_z and does not qualify fails with DSC_EINVAL (dsc_gemm_split_tile tells beforehand). */
+    const float* gnb_z; int64_t ld_gnb_z;
+    float* gnb_dgamma; float* gnb_dbeta; float* gnb_dbias; int64_t gnb_pstride;
+    float* gnb_dss; int64_t ld_gnb_dss;
 } dsc_gemm_args;
 #define DSC_PLANES_ROWMAJOR 0
 #define DSC_PLANES_FRAGMENT 1

@@ -146,3 +146,67 @@ def test_wrong_plane_layout_is_an_error():
     ops.attach_planes(g, pl, layout=ops.PLANES_ROWMAJOR)        # claims row-major where the launch wants fragment-major
     with pytest.raises(RuntimeError, match="dsc_gemm_f32"):
         ops.run_gemm(g)
+
+
+@pytest.mark.parametrize("N,mode", [(80, 2), (80, 0), (70, 2)])
+def test_groupnorm_backward_epilogue_matches_the_two_launch_form(N, mode):
+    """dsc_gemm_f32 with the GroupNorm-backward epilogue (gnb_*: the input-gradient GEMM of the NEXT layer writes the gradient w.r.t. a fused Block's
+    pre-norm activation, its per-scene partial sums and d(scale, shift)) against the two launches it replaces -- the same product without the
+    epilogue, then dsc_gn_silu_bwd_f32 -- and against an f64 evaluation of the same formulas."""
+    from diffuscene_amd import _lib, ops
+    d, scenes, n, K = dev(), 256, 512, 512
+    M = scenes * N
+    dy2, w = rnd(M, K, seed=41), rnd(n, K, seed=42, scale=0.06)          # dh = dy2 . w^T
+    z, gamma, beta = rnd(M, n, seed=43, scale=2.0), rnd(n, seed=44) + 1.5, rnd(n, seed=45)
+    ss = rnd(scenes, 2 * n, seed=46, scale=0.3) if mode == 2 else None
+    (pl,) = ops.split_planes([(w, None, False)])
+    dh = ops.gemm(dy2, w, None, w_planes=pl)
+    dz_ref, dg_ref, db_ref, dbias_ref, dss_ref = ops.gn_silu_bwd(z, dh, gamma, beta, ss, mode, scenes, N)
+    dz = torch.full((M, n), float("nan"), device=d)
+    part = torch.full((scenes, 3 * n), float("nan"), device=d)
+    dss = torch.full((scenes, 2 * n), float("nan"), device=d) if mode == 2 else None
+    pp = part.data_ptr()
+    g = ops.make_gemm_args(dy2, w, dz, gamma=gamma, beta=beta, tokens_per_scene=N, scale_shift=ss, ss_mode=mode,
+                           gnb=dict(z=z, dgamma=pp + 4 * n, dbeta=pp + 8 * n, dbias=pp, pstride=3 * n, dss=dss), w_planes=pl)
+    assert _lib.fn("dsc_gemm_split_tile")(g, 0) == _lib.TILE_WAVE_DENSE
+    ops.run_gemm(g)
+    red = part.double().sum(0)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    assert torch.isfinite(dz).all() and rel(dz, dz_ref) < 2e-6, rel(dz, dz_ref)
+    assert rel(red[:n], dbias_ref) < 1e-5 and rel(red[n:2 * n], dg_ref) < 1e-5 and rel(red[2 * n:], db_ref) < 1e-5
+    if mode == 2:
+        assert rel(dss, dss_ref) < 1e-5
+    # f64 evaluation of the formulas (train.hip: gn_silu_bwd_reg_kernel)
+    z64, dh64 = z.double().view(scenes, N, 8, 64), dh.double().view(scenes, N, 8, 64)
+    mu = z64.mean(dim=(1, 3), keepdim=True)
+    rs = 1.0 / torch.sqrt(z64.var(dim=(1, 3), unbiased=False, keepdim=True) + 1e-5)
+    xh = (z64 - mu) * rs
+    ga, be = gamma.double().view(1, 1, 8, 64), beta.double().view(1, 1, 8, 64)
+    s1 = 1.0 + (ss[:, :n].double().view(scenes, 1, 8, 64) if mode == 2 else 0.0)
+    sh = ss[:, n:].double().view(scenes, 1, 8, 64) if mode == 2 else 0.0
+    u = (ga * xh + be) * s1 + sh
+    sig = torch.sigmoid(u)
+    du = dh64 * (sig * (1 + u * (1 - sig)))
+    dxh = du * s1 * ga
+    want = rs * (dxh - dxh.mean(dim=(1, 3), keepdim=True) - xh * (dxh * xh).mean(dim=(1, 3), keepdim=True))
+    assert rel(dz, want.view(M, n)) < 5e-6
+
+
+def test_groupnorm_backward_epilogue_refuses_what_it_cannot_do():
+    """A launch that sets gnb_z and does not qualify (scenes of <= 64 tokens, a per-slot (scale, shift), too few waves) fails -- it is never run without the epilogue."""
+    from diffuscene_amd import ops
+    n, K = 512, 512
+    for scenes, N, mode in ((256, 21, 0), (256, 80, 3), (64, 80, 0)):
+        M = scenes * N
+        dy2, w, z = rnd(M, K, seed=1), rnd(n, K, seed=2, scale=0.05), rnd(M, n, seed=3)
+        gamma, beta = rnd(n, seed=4) + 1.5, rnd(n, seed=5)
+        ss = rnd(N, 2 * n, seed=6) if mode == 3 else None
+        dz, part = torch.empty(M, n, device=dev()), torch.empty(scenes, 3 * n, device=dev())
+        pp = part.data_ptr()
+        g = ops.make_gemm_args(dy2, w, dz, gamma=gamma, beta=beta, tokens_per_scene=N, scale_shift=ss, ss_mode=mode,
+                               gnb=dict(z=z, dgamma=pp + 4 * n, dbeta=pp + 8 * n, dbias=pp, pstride=3 * n, dss=None))
+        assert ops.planes_layout(g) == -1
+        with pytest.raises(RuntimeError, match="dsc_gemm_f32"):
+            ops.run_gemm(g)
