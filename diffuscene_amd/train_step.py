@@ -97,8 +97,10 @@ def plan_supported(model):
     d = model.diffusion.diffusion
     net = model.diffusion.model
     p = next(model.parameters())
-    if not p.is_cuda or model.room_mask_condition or model.room_partial_condition:
-        return False
+    if not p.is_cuda or model.room_mask_condition:
+        return False                    # the room-mask feature extractor is out of scope (networks/feature_extractors.py)
+    # room_partial_condition (reference :193-199; no shipped YAML sets it): fc_partial_condition(target * mask) is one more torch module
+    # in front of the plan, like fc_arrange_condition -- its rows enter as per-token context and its gradient leaves through d_ctx
     if d.loss_type != 'mse' or d.translation_dim != 3 or model.sample_num_points > 160:
         return False
     if not all(q.requires_grad for q in net.parameters()):

@@ -155,6 +155,9 @@ def test_train_on_batch_one_adam_step(case, golden_dir, tmp_path, cpu_rng):
     StatsLogger.instance().clear()
     torch.manual_seed(SEED_TRAIN)
     ret = train_on_batch(m, opt, s, {"training": {"max_grad_norm": 10}})
+    # every wrapper case -- the partial condition too (round 6) -- trains on the static plan, not on the autograd fallback
+    from diffuscene_amd.train_step import plan_supported
+    assert plan_supported(m) and getattr(m, "_dsc_plan_runner", None) is not None, case
     want = float(g[case + ".train.loss"])
     assert abs(ret - want) <= 1e-4 * abs(want), (case, ret, want)
     gn, wgn = StatsLogger.instance()["gradnorm"].value, float(g[case + ".train.gradnorm"])

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_wave_kernel<true, 5, false, 8>"      # (rounds 3-5: "gemm_split_kernel<true, 2, 4, 5")
+pat = sys.argv[2] if len(sys.argv) > 2 else "gemm_split_wave_kernel<true, 5, false, 8,"      # (rounds 3-5: "gemm_split_kernel<true, 2, 4, 5")
 out = os.path.join(ROOT, "gpurun_out")
 
 
@@ -75,6 +75,10 @@ if s:
         if dur:
             rec["mfma_busy"]["avg_duration_us"] = round(dur, 2)
             rec["mfma_busy"]["effective_clock_ghz"] = round(s["GRBM_GUI_ACTIVE"] / 8.0 / dur / 1e3, 3)
+if not (f and w and nf):
+    # a kernel rename must not publish an empty record (round 6: a new template parameter changed the name and the summary
+    # silently matched nothing)
+    sys.exit("pmc_summary: no dispatch matched %r in %s_pmc_fetch / _pmc_write -- update the pattern" % (pat, tag))
 path_tag = "_f32" if "gemm_kernel" in pat else ""
 path = os.path.join(out, "%s_gemm_gn_hbm_traffic%s.json" % (tag, path_tag))       # copy to profiles/rNN_gemm_gn_hbm_traffic.json to publish it
 with open(path, "w") as fh:
