@@ -18,6 +18,7 @@ SS_NONE, SS_PER_TOKEN, SS_PER_SCENE, SS_PER_SLOT, SS_BY_INDEX = 0, 1, 2, 3, 4
 MEAN_EPS, MEAN_X0, MEAN_V = 0, 1, 2
 TILE_GN_80_W8, TILE_GN_80_W4, TILE_160x256, TILE_160x128_W4 = 1, 2, 5, 8      # DSC_TILE_* (dsc_gemm_split_tile)
 TILE_WAVE_GN, TILE_WAVE_DENSE, TILE_WAVE_GN_64 = 10, 11, 12
+GEMM_ROW_INVARIANT = 1          # dsc_gemm_args.flags (include/diffuscene_hip.h)
 WS_MAX = 64
 MAX_TOKENS_PER_SCENE = 160
 
@@ -53,6 +54,7 @@ class GemmArgs(C.Structure):
         ("gnb_z", C.c_void_p), ("ld_gnb_z", C.c_int64),
         ("gnb_dgamma", C.c_void_p), ("gnb_dbeta", C.c_void_p), ("gnb_dbias", C.c_void_p), ("gnb_pstride", C.c_int64),
         ("gnb_dss", C.c_void_p), ("ld_gnb_dss", C.c_int64),
+        ("flags", C.c_int32),
     ]
 
 
@@ -108,6 +110,9 @@ SIGNATURES = {
     "dsc_gemm_planes_layout": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
     "dsc_get_split_wave": (C.c_int, []),
     "dsc_set_split_wave": (C.c_int, [C.c_int32]),
+    "dsc_gemm_skinny": (C.c_int, [C.POINTER(GemmArgs), C.c_int32]),
+    "dsc_get_skinny": (C.c_int, []),
+    "dsc_set_skinny": (C.c_int, [C.c_int32]),
     "dsc_get_gemm_arithmetic": (C.c_int, []),
     "dsc_set_gemm_arithmetic": (C.c_int, [C.c_int32]),
     "dsc_gemm_layernorm_f32": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),

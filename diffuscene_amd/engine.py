@@ -101,8 +101,8 @@ class Plan:
         return out
 
     # ---- step emitters -------------------------------------------------------------------------
-    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE):
-        g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out)
+    def gemm(self, a, w, out, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE, row_invariant=False):
+        g = ops.make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out, row_invariant=row_invariant)
         lay = ops.planes_layout(g)                       # planes only for launches that will use them, in the layout their kernel reads
         pl = self.eng.planes_of(w, lay) if lay >= 0 else None
         if pl is not None:
@@ -285,10 +285,11 @@ class Plan:
             temb = pool.get(B, D)
             self.call("dsc_time_embedding_f32", self.t_in.data_ptr(), B, D, e.time_table.data_ptr(),
                       e.time_table.shape[0], e.time_freq.data_ptr(), temb.data_ptr(), keep=(temb,))
-            t1 = self.gemm(temb, net.time_mlp[1].weight, pool.get(B, 4 * D), net.time_mlp[1].bias, act_out=ACT_GELU)
+            # row_invariant: ss_table() below builds the same rows with m = T for the captured loops -- both must take the same kernel
+            t1 = self.gemm(temb, net.time_mlp[1].weight, pool.get(B, 4 * D), net.time_mlp[1].bias, act_out=ACT_GELU, row_invariant=True)
             # every consumer applies SiLU first (ResnetBlock.mlp) -> fold it into this epilogue
-            t2 = self.gemm(t1, net.time_mlp[3].weight, pool.get(B, 4 * D), net.time_mlp[3].bias, act_out=ACT_SILU)
-            self.ss_t = self.gemm(t2, e.t_pack_w, pool.get(B, e.t_pack_w.shape[0]), e.t_pack_b)
+            t2 = self.gemm(t1, net.time_mlp[3].weight, pool.get(B, 4 * D), net.time_mlp[3].bias, act_out=ACT_SILU, row_invariant=True)
+            self.ss_t = self.gemm(t2, e.t_pack_w, pool.get(B, e.t_pack_w.shape[0]), e.t_pack_b, row_invariant=True)
         if self.ctx_in is not None:
             first = len(self.steps)
             cact = pool.get(self.ctx_in.shape[0], self.ctx_in.shape[1])       # SiLU of ResnetBlock.mlp (:181-184), once
@@ -574,9 +575,9 @@ class DenoiserEngine:
         if self._ss_table_sig != self.sig:
             net = self.net
             with torch.no_grad():
-                t1 = ops.gemm(self.time_table, net.time_mlp[1].weight, net.time_mlp[1].bias, act_out=ACT_GELU)
-                t2 = ops.gemm(t1, net.time_mlp[3].weight, net.time_mlp[3].bias, act_out=ACT_SILU)
-                ops.gemm(t2, self.t_pack_w, self.t_pack_b, out=self._ss_table)
+                t1 = ops.gemm(self.time_table, net.time_mlp[1].weight, net.time_mlp[1].bias, act_out=ACT_GELU, row_invariant=True)
+                t2 = ops.gemm(t1, net.time_mlp[3].weight, net.time_mlp[3].bias, act_out=ACT_SILU, row_invariant=True)
+                ops.gemm(t2, self.t_pack_w, self.t_pack_b, out=self._ss_table, row_invariant=True)
             self._ss_table_sig = self.sig
         return self._ss_table
 

@@ -41,7 +41,7 @@ def as2d(w):
 
 def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE,
                    gamma=None, beta=None, eps=1e-5, tokens_per_scene=0, scale_shift=None, ss_mode=SS_NONE, preact=None,
-                   ss_index=None, w_planes=None, actgrad_x=None, gnb=None):
+                   ss_index=None, w_planes=None, actgrad_x=None, gnb=None, row_invariant=False):
     """Build a dsc_gemm_args for  y = epi(act_in([a|a2]) @ w.T + bias).  The returned struct holds raw
     pointers only; the caller keeps the tensors alive.  ``w_planes``: the weight pre-split into bf16 planes (split_planes):
     the product runs on the bf16 matrix cores with f32 accuracy where the kernel supports the shape."""
@@ -66,6 +66,8 @@ def make_gemm_args(a, w, y, bias=None, a2=None, residual=None, act_in=ACT_NONE, 
     if residual is not None:
         g.residual, g.ldr = _mat(residual, "residual")
     g.act_in, g.act_out, g.batch = act_in, act_out, 1
+    if row_invariant:                      # include/diffuscene_hip.h DSC_GEMM_ROW_INVARIANT: a row's result must not depend on the number of rows
+        g.flags |= _lib.GEMM_ROW_INVARIANT
     if gamma is not None:
         g.gamma, g.beta, g.eps = _dev(gamma).data_ptr(), _dev(beta).data_ptr(), eps
         g.tokens_per_scene = tokens_per_scene
@@ -188,11 +190,11 @@ def run_gemm(g, gn=False, stream=None):
     _lib.check(_lib.fn(name)(C.byref(g), stream if stream is not None else stream_ptr()), name)
 
 
-def gemm(a, w, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None, w_planes=None):
+def gemm(a, w, bias=None, a2=None, residual=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None, w_planes=None, row_invariant=False):
     w2 = as2d(w)
     if out is None:
         out = torch.empty((a.shape[0], w2.shape[0]), device=a.device, dtype=torch.float32)
-    run_gemm(make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out, w_planes=w_planes))
+    run_gemm(make_gemm_args(a, w, out, bias, a2, residual, act_in, act_out, w_planes=w_planes, row_invariant=row_invariant))
     return out
 
 

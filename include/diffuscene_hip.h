@@ -111,7 +111,13 @@ typedef struct dsc_gemm_args {
     const float* gnb_z; int64_t ld_gnb_z;
     float* gnb_dgamma; float* gnb_dbeta; float* gnb_dbias; int64_t gnb_pstride;
     float* gnb_dss; int64_t ld_gnb_dss;
+    /* DSC_GEMM_ROW_INVARIANT: every output row must come out exactly as in a launch of the same product with any other number of rows --
+     * a table built once with m = T rows stands in for per-step launches with m = B rows (the tabulated time MLP of the reverse loops,
+     * engine.ss_table), and a captured loop must reproduce the eager loop bit for bit.  The launch then stays on the exact-f32 tile
+     * kernels, whose K order does not depend on m (the K-parallel kernel for small launches associates the K sum differently). */
+    int32_t flags;
 } dsc_gemm_args;
+#define DSC_GEMM_ROW_INVARIANT 1
 #define DSC_PLANES_ROWMAJOR 0
 #define DSC_PLANES_FRAGMENT 1
 
@@ -151,6 +157,16 @@ int dsc_gemm_planes_layout(const dsc_gemm_args* args, int32_t gn);
  * else -> DSC_EINVAL from get and from every GEMM launch).  Both families compute bit-identical results (tests/test_gpu_split.py). */
 int dsc_get_split_wave(void);
 int dsc_set_split_wave(int32_t mode);
+
+/* The K-parallel exact-f32 kernel for launches too small to fill the chip (csrc/gemm_skinny.h, round 6): a block owns <= 32 token rows
+ * (whole scenes) x 64 channels and splits K over its eight waves.  It takes a launch of dsc_gemm_f32 / dsc_gemm_gn_silu_f32 that stays on
+ * the exact-f32 arithmetic when (k1 + k2) % 64 == 0, n % 64 == 0, scenes of <= 32 tokens, 16-byte aligned rows and ALL blocks fit one
+ * round of the chip (the one-scene generation call of scripts/generate_diffusion.py:314-323, batches of a few scenes) -- same
+ * products, the K sum associated as eight slice sums.  dsc_gemm_skinny: 0 = a tile kernel (or the split family) takes the launch,
+ * 1 = this kernel.  Switch: 1 = on (default), 0 = off; initial value from DSC_SKINNY ("0" -> off). */
+int dsc_gemm_skinny(const dsc_gemm_args* args, int32_t gn);
+int dsc_get_skinny(void);
+int dsc_set_skinny(int32_t on);   /* returns the previous setting */
 
 /* The arithmetic switch of dsc_gemm_f32 / dsc_gemm_gn_silu_f32 / the grouped weight-gradient launch chosen by the host code -- the ONE
  * source of truth (the Python engine, the training plan and bench.py ask this function, nothing else parses the environment):

@@ -224,7 +224,10 @@ def test_split_path_falls_back_where_it_does_not_apply():
     (pl,) = ops.split_planes([(w, None, False)])
     out = torch.zeros(300, 200, device=d)
     y1 = ops.gemm(a, w, b, out=out[:, 3:131], w_planes=pl).clone()         # unaligned column offset
-    assert torch.equal(y1, ops.gemm(a, w, b))
+    # (same output alignment on both sides: an aligned launch of this size may run the K-parallel exact-f32 kernel of round 6, whose K sum
+    # is associated differently from the tile kernel an unaligned output stays on -- tests/test_gpu_skinny.py compares those two)
+    assert torch.equal(y1, ops.gemm(a, w, b, out=torch.zeros(300, 200, device=d)[:, 3:131]))
+    assert (y1 - ops.gemm(a, w, b)).abs().max() <= 5e-6 * y1.abs().max()
     assert torch.equal(ops.gemm(a[:100], w, b, w_planes=pl), ops.gemm(a[:100], w, b))      # < 256 rows
     for N in (12, 96):
         M = 8 * N

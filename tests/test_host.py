@@ -356,3 +356,24 @@ def test_guard_allocator_is_built_and_exports_the_pluggable_allocator_entry_poin
     lib = ctypes.CDLL(so)
     for name in ("guard_malloc", "guard_free", "guard_check", "guard_stats", "guard_mode"):
         assert getattr(lib, name) is not None
+
+
+def test_gemm_args_ctypes_mirror_matches_the_header(tmp_path):
+    """The ctypes mirror of dsc_gemm_args (diffuscene_amd/_lib.GemmArgs) has the size and the field offsets the C compiler gives the
+    header's struct (a field added on one side only would shift every pointer behind it)."""
+    import ctypes
+    import subprocess
+    from diffuscene_amd import _lib
+    names = [f[0] for f in _lib.GemmArgs._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "diffuscene_hip.h"', 'int main(void) {',
+             '  printf("%zu\\n", sizeof(dsc_gemm_args));']
+    lines += ['  printf("%%zu\\n", offsetof(dsc_gemm_args, %s));' % n for n in names]
+    lines += ['  return 0; }']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_lib.GemmArgs), (out[0], ctypes.sizeof(_lib.GemmArgs))
+    for n, off in zip(names, out[1:]):
+        assert getattr(_lib.GemmArgs, n).offset == off, (n, off, getattr(_lib.GemmArgs, n).offset)
