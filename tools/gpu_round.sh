@@ -34,6 +34,10 @@ pmctrain) cd /tmp && export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmct_write -o w -- python $R/bench.py --mode train --steps 2 --warmup 2 --no-cpu-baseline > $O/${TAG}_pmct_write.log 2>&1
   cd $R; for k in sq fetch write; do python tools/rocpd_summary.py $(find $O/${TAG}_pmct_$k -name "*.db" | head -1) > $O/${TAG}_train_pmc_$k.txt 2>&1; done
   python tools/pmc_train_summary.py $TAG > $O/${TAG}_train_pmc.txt 2>&1; head -30 $O/${TAG}_train_pmc.txt ;;
+skinny) # the K-parallel small-launch GEMM: phase stamps (staged form, then the direct-fragment form it replaced), the B = 1 plan with the kernel off / on
+  ( for k in 512 1024; do ./tools/skinny_probe 1 $k 21 1 400 1; ./tools/skinny_probe 1 $k 21 1 400 1 0 1; done; ./tools/skinny_probe 0 512 21 1 400 1; ./tools/skinny_probe 0 3072 21 1 400 1; ./tools/skinny_probe 1 512 12 4 400 1 ) > $O/${TAG}_skinny_probe.txt 2>&1
+  for s in 0 1; do echo "== DSC_SKINNY=$s"; DSC_SKINNY=$s timeout 300 python tools/plan_profile.py bedroom21 --batch 1 2>&1 | grep -v amdgpu.ids; done > $O/${TAG}_plan_b1_skinny.txt 2>&1
+  grep "launches, sum\|us per launch" $O/${TAG}_plan_b1_skinny.txt $O/${TAG}_skinny_probe.txt | head -30 ;;
 guard) rm -f $O/${TAG}_guard.log; timeout 300 python tools/stale_plan_repro.py arrange > $O/${TAG}_stale_plan_repro.txt 2> $O/${TAG}_stale_plan_repro.err; cat $O/${TAG}_stale_plan_repro.txt | cut -c1-700
   DSC_GUARD_LOG=$O/${TAG}_guard.log timeout 1500 python -m pytest tests/test_gpu_guard.py -q -x --durations=8 > $O/${TAG}_guard_tests.log 2>&1; tail -25 $O/${TAG}_guard_tests.log ;;
 guard20) timeout 1500 python tools/guard_run.py --mode normal --loops 20 --T 3 --train-steps 3 --out $O/${TAG}_guard_loops20.json > /dev/null 2> $O/${TAG}_guard_loops20.log; tail -4 $O/${TAG}_guard_loops20.log | cut -c1-400 ;;
