@@ -75,16 +75,17 @@ int skinny_enabled() {
     return g_skinny;
 }
 
-struct SkinnyPlan { int rows_per_blk, ng, rt, nrb, ncb; };
+struct SkinnyPlan { int rows_per_blk, ng, nrb, ncb; };
 
 // Does the K-parallel kernel take this launch?  Shape: K % 64 == 0 (eight slices of whole 8-k units), a K slice inside one operand
-// segment, n % 64 == 0, whole scenes of <= 32 tokens, 16-byte aligned rows everywhere, and ALL blocks in one round of the chip -- beyond
-// that the tile kernels' throughput wins over this kernel's latency.  Blocks of 32 rows x 8 K slices where they fit one round; else
-// blocks of 64 rows (4 K slices x 2 row tiles, the LDS-staged form: K % 256 == 0) -- the 128 x 12 text configuration.
+// segment, n % 64 == 0, whole scenes of <= 32 tokens per block, 16-byte aligned rows everywhere, and ALL blocks in one round of the
+// chip -- beyond that the tile kernels' throughput wins over this kernel's latency (measured on the 128 x 12 text configuration with a
+// 64-row form of this kernel: 21 us against the tile kernel's 19.5 us per GroupNorm launch; that form is gone).
 bool skinny_plan(const dsc_gemm_args* a, bool gn, SkinnyPlan* out) {
     if (!skinny_enabled() || (a->flags & DSC_GEMM_ROW_INVARIANT)) return false;
     const int K = a->k1 + a->k2;
     if ((K % 64) || (a->n % 64)) return false;
+    if (a->k2 > 0 && (a->k1 % (K / dsc_skinny::NW))) return false;
     if (a->preact && !gn) return false;
     if (a->actgrad_x || a->gnb_z) return false;
     int unit = 1;                                   // rows come in whole scenes under GroupNorm
@@ -94,43 +95,33 @@ bool skinny_plan(const dsc_gemm_args* a, bool gn, SkinnyPlan* out) {
         if (unit > 32) return false;
     }
     const int ncb = a->n / 64;
-    int rt = 0, rpb = 0;
-    int64_t nrb = 0;
-    for (int cand = 1; cand <= 2 && !rt; ++cand) {
-        const int nks = dsc_skinny::NW / cand;
-        if (cand == 2 && (K % (64 * nks))) break;                       // two row tiles: slices of whole 64-k chunks (the staged form)
-        if (a->k2 > 0 && (a->k1 % (K / nks))) continue;
-        int r = (32 * cand / unit) * unit;
-        if (r > a->m) r = (int)(((int64_t)a->m + unit - 1) / unit * unit);
-        if (cand == 2 && r <= 32) break;
-        const int64_t nb = ((int64_t)a->m + r - 1) / r;
-        if (nb * ncb * a->batch <= 256) { rt = cand; rpb = r; nrb = nb; }
-    }
-    if (!rt) return false;
+    int rpb = (32 / unit) * unit;
+    if (rpb > a->m) rpb = (int)(((int64_t)a->m + unit - 1) / unit * unit);
+    const int64_t nrb = ((int64_t)a->m + rpb - 1) / rpb;
+    if (nrb * ncb * a->batch > 256) return false;
     auto al = [](const void* q) { return !q || dsc_aligned16(q); };
     if (!al(a->y) || !al(a->residual) || !al(a->bias) || !al(a->preact) || !al(a->gamma) || !al(a->beta) || !al(a->scale_shift)) return false;
     if ((a->ldy & 3) || (a->residual && (a->ldr & 3)) || (a->preact && (a->ld_preact & 3)) || (a->scale_shift && (a->ld_ss & 3))) return false;
     if (a->batch > 1 && ((a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return false;
     out->rows_per_blk = rpb;
-    out->rt = rt;
     // K slices of whole 64-k chunks: the LDS-staged form; else fragments straight from global memory (register-resident up to K = 1024)
-    out->ng = (rt == 2 || (K % 512) == 0) ? dsc_skinny::STAGED : K <= 256 ? 1 : K <= 512 ? 2 : K <= 1024 ? 4 : 0;
+    out->ng = (K % 512) == 0 ? dsc_skinny::STAGED : K <= 256 ? 1 : K <= 512 ? 2 : K <= 1024 ? 4 : 0;
     out->nrb = (int)nrb;
     out->ncb = ncb;
     return true;
 }
 
-template <bool GN, int NG, int RT>
+template <bool GN, int NG>
 int launch_skinny_ng(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsc_skinny::gemm_skinny_kernel<GN, NG, RT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsc_skinny::gemm_skinny_kernel<GN, NG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsc_skinny::lds_bytes<NG>());
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((dsc_skinny::gemm_skinny_kernel<GN, NG, RT>), dim3((unsigned)(sp.nrb * sp.ncb), (unsigned)a->batch),
+    hipLaunchKernelGGL((dsc_skinny::gemm_skinny_kernel<GN, NG>), dim3((unsigned)(sp.nrb * sp.ncb), (unsigned)a->batch),
                        dim3(64 * dsc_skinny::NW), dsc_skinny::lds_bytes<NG>(), s, *a, sp.ncb, sp.rows_per_blk);
     DSC_LAUNCH_CHECK();
     return 0;
@@ -138,13 +129,12 @@ int launch_skinny_ng(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s
 
 template <bool GN>
 int launch_skinny(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s) {
-    if (sp.rt == 2) return launch_skinny_ng<GN, dsc_skinny::STAGED, 2>(a, sp, s);
     switch (sp.ng) {
-        case 1: return launch_skinny_ng<GN, 1, 1>(a, sp, s);
-        case 2: return launch_skinny_ng<GN, 2, 1>(a, sp, s);
-        case 4: return launch_skinny_ng<GN, 4, 1>(a, sp, s);
-        case dsc_skinny::STAGED: return launch_skinny_ng<GN, dsc_skinny::STAGED, 1>(a, sp, s);
-        default: return launch_skinny_ng<GN, 0, 1>(a, sp, s);
+        case 1: return launch_skinny_ng<GN, 1>(a, sp, s);
+        case 2: return launch_skinny_ng<GN, 2>(a, sp, s);
+        case 4: return launch_skinny_ng<GN, 4>(a, sp, s);
+        case dsc_skinny::STAGED: return launch_skinny_ng<GN, dsc_skinny::STAGED>(a, sp, s);
+        default: return launch_skinny_ng<GN, 0>(a, sp, s);
     }
 }
 
@@ -152,11 +142,11 @@ int launch_skinny(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s) {
 
 extern "C" int dsc_get_skinny(void) { return skinny_enabled(); }
 extern "C" int dsc_set_skinny(int32_t on) { const int prev = skinny_enabled(); g_skinny = on ? 1 : 0; return prev; }
-// 0: a tile kernel (or the split-bf16 family) takes the launch; 1 / 2: the K-parallel kernel with blocks of one / two 32-row tiles
+// 0: a tile kernel (or the split-bf16 family) takes the launch; 1: the K-parallel kernel
 extern "C" int dsc_gemm_skinny(const dsc_gemm_args* a, int32_t gn) {
     if (check_common(a) || dsc_gemm_arithmetic(a, gn)) return 0;
     SkinnyPlan sp;
-    return skinny_plan(a, gn != 0, &sp) ? sp.rt : 0;
+    return skinny_plan(a, gn != 0, &sp) ? 1 : 0;
 }
 
 // Tile choice: estimated time ~ ceil(blocks / 256 CUs) * tile area (every CU works through its blocks); ties go to the

@@ -58,15 +58,12 @@ constexpr size_t lds_bytes() { return sizeof(float) * (size_t)(NW * wave_lds<NG>
 //     fragments are in registers; the partial tiles later reuse the same bytes.
 //   1, 2, 4 -- fragments straight from global memory, the whole slice in NG register buffers of 32 k (K <= 256 NG), every load issued
 //     before the first MFMA; 0 -- the same with two buffers in flight, any K.  (K = 128, 384, 3072 ...)
-template <bool GN, int NG, int RT = 1>
+template <bool GN, int NG>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_args p, int ncolblk, int rows_per_blk) {
-    static_assert(RT == 1 || (RT == 2 && NG == STAGED), "two row tiles per block: the LDS-staged form only");
-    constexpr int NKS = NW / RT;                 // K slices: the block's waves are NKS slices x RT row tiles
     extern __shared__ float smem[];
     DSC_SKINNY_STAMP_DECL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int ks = wave % NKS, rtw = wave / NKS; // this wave's K slice and row tile
     const int z = blockIdx.y;
     const int rb = blockIdx.x / ncolblk, cb = blockIdx.x % ncolblk;
     const int64_t row0 = (int64_t)rb * rows_per_blk;
@@ -80,18 +77,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
     const float* res = p.residual ? p.residual + (int64_t)z * p.sres : nullptr;
     float* y = p.y + (int64_t)z * p.sy;
 
-    // ---- this wave's K slice (inside ONE operand segment: the host checks k1 % (K / NKS) == 0 when there are two)
+    // ---- this wave's K slice (inside ONE operand segment: the host checks k1 % (K / 8) == 0 when there are two)
     const int K = p.k1 + p.k2;
-    const int KS = K / NKS;
+    const int KS = K / NW;
     const int U = KS >> 3;                       // units of 8 k
-    const int kbeg = ks * KS;
+    const int kbeg = wave * KS;
     const float* ab;
     int64_t lda;
     int ka;
     if (kbeg < p.k1) { ab = a1; lda = p.lda1; ka = kbeg; }
     else             { ab = a2; lda = p.lda2; ka = kbeg - p.k1; }
     // rows past the end read row 0 of the block: their accumulators are never stored
-    const float* ap = ab + (row0 + (rtw * 32 + l31 < rows_here ? rtw * 32 + l31 : 0)) * lda + ka + 4 * half;
+    const float* ap = ab + (row0 + (l31 < rows_here ? l31 : 0)) * lda + ka + 4 * half;
     const float* wp[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) wp[ct] = w + (int64_t)(col0 + ct * 32 + l31) * p.ldw + kbeg + 4 * half;
@@ -125,45 +122,32 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
         }
     };
 
-    // ---- row layout of the epilogue: thread = (token row r of each row tile, channel quad cq).  Everything the epilogue reads that does not
-    // depend on the product -- bias, GroupNorm affine, the (scale, shift) row, the residual quad -- is requested right behind the operand loads
-    // and lands under the MFMAs: at this size a launch is a chain of memory latencies
+    // ---- row layout of the epilogue: thread = (token row r, channel quad cq).  Everything the epilogue reads that does not depend on the
+    // product -- bias, GroupNorm affine, the (scale, shift) row, the residual quad -- is requested right behind the operand loads and lands
+    // under the MFMAs: at this size a launch is a chain of memory latencies, and each one taken off the chain is ~1 us of a ~10 us launch
     const int cq = tid & 15, r = tid >> 4;
     const int c = col0 + cq * 4;
+    const bool ok = r < rows_here;
+    const int64_t tok = row0 + r;
     const int N = GN ? p.tokens_per_scene : 1;
+    const int sc = (GN && ok) ? r / N : 0;
     const int64_t scene0 = GN ? row0 / N : 0;
-    bool ok[RT];
-    int64_t tok[RT];
-    int sc[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        ok[rt] = rt * 32 + r < rows_here;
-        tok[rt] = row0 + rt * 32 + r;
-        sc[rt] = (GN && ok[rt]) ? (rt * 32 + r) / N : 0;
-    }
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, ga = b4, be = b4;
-    f32x4 r4[RT], sc4[RT], sh4[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) r4[rt] = sc4[rt] = sh4[rt] = b4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, r4 = b4, ga = b4, be = b4, sc4 = b4, sh4 = b4;
     auto prefetch_epilogue = [&]() {
         if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + c);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-            if (res && ok[rt]) r4[rt] = *reinterpret_cast<const f32x4*>(res + tok[rt] * p.ldr + c);
+        if (res && ok) r4 = *reinterpret_cast<const f32x4*>(res + tok * p.ldr + c);
         if constexpr (GN) {
             ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
             be = *reinterpret_cast<const f32x4*>(p.beta + c);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-                if (p.scale_shift && ok[rt]) {
-                    const int64_t srow = p.ss_mode == DSC_SS_PER_TOKEN ? tok[rt]
-                                       : p.ss_mode == DSC_SS_PER_SCENE ? scene0 + sc[rt]
-                                       : p.ss_mode == DSC_SS_PER_SLOT  ? (int64_t)((rt * 32 + r) % N)
-                                       : dsc_clamp_index(p.ss_index[scene0 + sc[rt]], p.ss_rows);
-                    const float* ss = p.scale_shift + srow * p.ld_ss + c;
-                    sc4[rt] = *reinterpret_cast<const f32x4*>(ss);
-                    sh4[rt] = *reinterpret_cast<const f32x4*>(ss + p.n);
-                }
+            if (p.scale_shift && ok) {
+                const int64_t srow = p.ss_mode == DSC_SS_PER_TOKEN ? tok
+                                   : p.ss_mode == DSC_SS_PER_SCENE ? scene0 + sc
+                                   : p.ss_mode == DSC_SS_PER_SLOT  ? (int64_t)(r % N)
+                                   : dsc_clamp_index(p.ss_index[scene0 + sc], p.ss_rows);
+                const float* ss = p.scale_shift + srow * p.ld_ss + c;
+                sc4 = *reinterpret_cast<const f32x4*>(ss);
+                sh4 = *reinterpret_cast<const f32x4*>(ss + p.n);
+            }
         }
     };
 
@@ -178,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
         int64_t aoff[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int rr = rtw * 32 + 4 * i + rsub;         // rows past the end read row 0 of the block: their accumulators are never stored
+            const int rr = 4 * i + rsub;                    // rows past the end read row 0 of the block: their accumulators are never stored
             aoff[i] = (row0 + (rr < rows_here ? rr : 0)) * lda + ka + seg * 4;
         }
         f32x4 qa[8], qw[2][8];
@@ -198,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
         gload_w(0, 0);
         gload_a(0);
         gload_w(1, 0);
-        if constexpr (RT == 1) prefetch_epilogue();
+        prefetch_epilogue();
         DSC_SKINNY_STAMP_LOADED
         for (int ch = 0; ch < nch; ++ch) {
             f32x4 fa[8], fw[8];
@@ -230,7 +214,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
                 for (int e = 0; e < 4; ++e) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fw[u][e], fa[u][e], acc[1], 0, 0, 0);
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (RT > 1) prefetch_epilogue();          // (two row tiles: the staging registers are free now; the requests land under the reduction)
     } else if constexpr (NG > 0) {
         f32x4 xa[NG][UG], xw[NG][2][UG];
 #pragma unroll
@@ -258,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
     }
 
     DSC_SKINNY_STAMP(1)
-    // ---- the partial tiles meet in LDS: wave w's bytes, [ct][token][channel]; MFMA layout: lane = token l31, acc[4 q + e] = channel
+    // ---- the eight partial tiles meet in LDS: wave w's bytes, [ct][token][channel]; MFMA layout: lane = token l31, acc[4 q + e] = channel
     // 8 q + 4 half + e
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -270,36 +253,31 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
     __syncthreads();
     DSC_SKINNY_STAMP(2)
 
-    // ---- fixed summation order over the K slices of each row tile
-    f32x4 v[RT];
+    // ---- fixed summation order over the waves
+    f32x4 v;
+    {
+        const float* t = smem + (cq >> 3) * (32 * TLD) + r * TLD + (cq & 7) * 4;
+        v = *reinterpret_cast<const f32x4*>(t);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const float* t = smem + (rt * NKS) * wave_lds<NG>() + (cq >> 3) * (32 * TLD) + r * TLD + (cq & 7) * 4;
-        v[rt] = *reinterpret_cast<const f32x4*>(t);
-#pragma unroll
-        for (int wv = 1; wv < NKS; ++wv) v[rt] += *reinterpret_cast<const f32x4*>(t + wv * wave_lds<NG>());
-        v[rt] += b4;
+        for (int wv = 1; wv < NW; ++wv) v += *reinterpret_cast<const f32x4*>(t + wv * wave_lds<NG>());
     }
+    v += b4;
     DSC_SKINNY_STAMP(3)
 
     if constexpr (!GN) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if (!ok[rt]) continue;
-            f32x4 o = v[rt];
+        if (ok) {
             if (p.act_out != DSC_ACT_NONE) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = dsc_act(o[e], p.act_out);
+                for (int e = 0; e < 4; ++e) v[e] = dsc_act(v[e], p.act_out);
             }
-            if (res) o += r4[rt];
-            *reinterpret_cast<f32x4*>(y + tok[rt] * p.ldy + c) = o;
+            if (res) v += r4;
+            *reinterpret_cast<f32x4*>(y + tok * p.ldy + c) = v;
         }
     } else {
         // GroupNorm over (tokens of a scene) x (the 64 channels of this block), two passes (mean, then the centred sum of squares)
-        float* S = smem + NW * wave_lds<NG>();         // [64] per-row sums
-        float* Q = S + 64;                             // [64] per-row centred sums of squares
-        float* MU = Q + 64;                            // [16] per-scene mean
-        float* RS = MU + 16;                           // [16] per-scene 1 / sqrt(var + eps)
+        float* S = smem + NW * wave_lds<NG>();         // [32] per-row sums (pass 1) / centred sums of squares (pass 2)
+        float* MU = S + 64;                            // [8] per-scene mean
+        float* RS = MU + 16;                           // [8] per-scene 1 / sqrt(var + eps)
         const int spt = rows_here / N;
         const float inv_cnt = 1.0f / (64.0f * (float)N);
         auto row16 = [](float x) {                     // sum over the 16 lanes (channel quads) of a token row
@@ -309,11 +287,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
             x += __shfl_xor(x, 8, 64);
             return x;
         };
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if (p.preact && ok[rt]) *reinterpret_cast<f32x4*>(p.preact + (int64_t)z * p.sy + tok[rt] * p.ld_preact + c) = v[rt];
-            const float s = row16(ok[rt] ? (v[rt][0] + v[rt][1]) + (v[rt][2] + v[rt][3]) : 0.f);
-            if (cq == 0) S[rt * 32 + r] = s;
+        if (p.preact && ok) *reinterpret_cast<f32x4*>(p.preact + (int64_t)z * p.sy + tok * p.ld_preact + c) = v;
+        {
+            const float s = row16(ok ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f);
+            if (cq == 0) S[r] = s;
         }
         __syncthreads();
         for (int st = wave; st < spt; st += NW) {
@@ -322,43 +299,39 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
             if (lane == 0) MU[st] = s * inv_cnt;
         }
         __syncthreads();
-        float mu[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            mu[rt] = MU[sc[rt]];
+        const float mu = MU[sc];
+        {
             float q = 0.f;
-            if (ok[rt]) {
+            if (ok) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[rt][e] - mu[rt]; q += d * d; }
+                for (int e = 0; e < 4; ++e) { const float d = v[e] - mu; q += d * d; }
             }
             q = row16(q);
-            if (cq == 0) Q[rt * 32 + r] = q;
+            if (cq == 0) S[32 + r] = q;
         }
         __syncthreads();
         for (int st = wave; st < spt; st += NW) {
-            float q = lane < N ? Q[st * N + lane] : 0.f;
+            float q = lane < N ? S[32 + st * N + lane] : 0.f;
             q = wave_sum_dpp(q);
             if (lane == 0) RS[st] = 1.0f / sqrtf(q * inv_cnt + p.eps);
         }
         __syncthreads();
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if (!ok[rt]) continue;
-            const float rs = RS[sc[rt]];
+        if (ok) {
+            const float rs = RS[sc];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a = rs * ga[e];
-                o[e] = v[rt][e] * a + (be[e] - mu[rt] * a);           // (z - mu) rstd gamma + beta, as gemm_core.h
+                o[e] = v[e] * a + (be[e] - mu * a);                   // (z - mu) rstd gamma + beta, as gemm_core.h
             }
             if (p.scale_shift) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = o[e] * (sc4[rt][e] + 1.0f) + sh4[rt][e];
+                for (int e = 0; e < 4; ++e) o[e] = o[e] * (sc4[e] + 1.0f) + sh4[e];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = dsc_silu_fast(o[e]);
-            if (res) o += r4[rt];
-            *reinterpret_cast<f32x4*>(y + tok[rt] * p.ldy + c) = o;
+            if (res) o += r4;
+            *reinterpret_cast<f32x4*>(y + tok * p.ldy + c) = o;
         }
     }
     DSC_SKINNY_STAMP_END

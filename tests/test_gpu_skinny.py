@@ -3,8 +3,7 @@ gemm_core.h it replaces there and against an fp64 evaluation of the same epilogu
 
 Both kernels multiply the same f32 operands with v_mfma_f32_32x32x2_f32; the K-parallel kernel associates the K sum as eight slice sums,
 so the two agree to f32 rounding of a K-long sum (held here to 5e-6 of the output scale, and each to 1e-5 of fp64), not bit for bit.
-Shapes: the one-scene generation call (B = 1, N = 12 / 21), a handful of scenes, the 128 x 12 text configuration (blocks of two row tiles),
-ragged rows, launches it must leave alone,
+Shapes: the one-scene generation call (B = 1, N = 12 / 21), a handful of scenes, ragged rows, launches it must leave alone,
 two K segments, every (scale, shift) mode, residual (also aliasing the output), saved pre-activation, grouped launches."""
 import pytest
 import torch
@@ -78,11 +77,8 @@ def test_plain_forms(m):
                 return sk, y
             (s0, y0), (s1, y1) = both(run)
             assert s0 == 0
-            K = k1 + k2
             if (-(-m // 32)) * (n // 64) <= 256:
                 assert s1 == 1, (m, n, k1, k2, s1)
-            elif m > 32 and K % 256 == 0 and (k2 == 0 or k1 % (K // 4) == 0) and (-(-m // 64)) * (n // 64) <= 256:
-                assert s1 == 2, (m, n, k1, k2, s1)          # blocks of two row tiles (4 K slices x 2 row tiles)
             else:
                 assert s1 == 0, (m, n, k1, k2, s1)          # more than one round of blocks: the tile kernels keep it
                 continue
@@ -110,7 +106,7 @@ def _gn64(z, N, gamma, beta, eps, ss_rows, res):
     return y + res if res is not None else y
 
 
-@pytest.mark.parametrize("N,scenes", [(12, 1), (21, 1), (12, 4), (21, 3), (12, 64), (12, 128), (12, 129), (21, 90), (33, 2), (32, 3), (5, 7), (4, 9), (5, 400)])
+@pytest.mark.parametrize("N,scenes", [(12, 1), (21, 1), (12, 4), (21, 3), (12, 64), (12, 128), (33, 2), (32, 3), (5, 7), (4, 9)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_groupnorm_forms(N, scenes, mode):
     """dsc_gemm_gn_silu_f32 (Block.forward as one launch): every (scale, shift) mode, residual, saved pre-activation, two K segments."""
@@ -138,11 +134,9 @@ def test_groupnorm_forms(N, scenes, mode):
             return sk, y, z
         (s0, y0, z0), (s1, y1, z1) = both(run)
         assert s0 == 0
-        r1, r2 = (32 // N) * N, (64 // N) * N
+        r1 = (32 // N) * N
         if r1 and -(-M // min(r1, M)) * 8 <= 256:
             assert s1 == 1, (N, scenes, s1)
-        elif r1 and min(r2, M) > 32 and (k1 + k2) % 256 == 0 and -(-M // min(r2, M)) * 8 <= 256:
-            assert s1 == 2, (N, scenes, s1)                # blocks of two row tiles: the 128 x 12 text configuration
         else:
             assert s1 == 0, (N, scenes, s1)                # scenes of more than 32 tokens / more than one round of blocks
             continue

@@ -1,6 +1,6 @@
 // Phase stamps and sustained timing of the K-parallel small-launch GEMM (csrc/gemm_skinny.h, round 6).  No torch: a gfx950 binary.
 //
-//   ./tools/skinny_probe [gn=1] [K=512] [N=21] [scenes=1] [reps=400] [wait=1] [loopform=0] [direct=0] [two=0]
+//   ./tools/skinny_probe [gn=1] [K=512] [N=21] [scenes=1] [reps=400] [wait=1] [loopform=0]
 //
 // Launches the kernel directly over R rotating operand sets (weights of R different layers, as a reverse step walks them), prints the sustained
 // us per launch from hipEvents and, from s_memtime stamps of every wave of block 0: launch -> operands requested+arrived -> MFMAs done -> partials
@@ -47,13 +47,13 @@ static float* dev_random(size_t n, float scale) {
     return d;
 }
 
-template <bool GN, int NG, int RT = 1>
+template <bool GN, int NG>
 static void run(const dsc_gemm_args* sets, int R, int reps, int ncb, int rpb, int nrb, hipStream_t s, const char* what) {
     using dsc_skinny::gemm_skinny_kernel;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<GN, NG, RT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<GN, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            (int)dsc_skinny::lds_bytes<NG>()));
     for (int i = 0; i < 20; ++i)
-        hipLaunchKernelGGL((gemm_skinny_kernel<GN, NG, RT>), dim3(nrb * ncb), dim3(512), dsc_skinny::lds_bytes<NG>(), s, sets[i % R], ncb, rpb);
+        hipLaunchKernelGGL((gemm_skinny_kernel<GN, NG>), dim3(nrb * ncb), dim3(512), dsc_skinny::lds_bytes<NG>(), s, sets[i % R], ncb, rpb);
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -61,7 +61,7 @@ static void run(const dsc_gemm_args* sets, int R, int reps, int ncb, int rpb, in
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, s));
         for (int i = 0; i < reps; ++i)
-            hipLaunchKernelGGL((gemm_skinny_kernel<GN, NG, RT>), dim3(nrb * ncb), dim3(512), dsc_skinny::lds_bytes<NG>(), s, sets[i % R], ncb, rpb);
+            hipLaunchKernelGGL((gemm_skinny_kernel<GN, NG>), dim3(nrb * ncb), dim3(512), dsc_skinny::lds_bytes<NG>(), s, sets[i % R], ncb, rpb);
         CK(hipEventRecord(e1, s));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -96,9 +96,7 @@ int main(int argc, char** argv) {
         }
         sets[r] = g;
     }
-    const int two = argc > 9 ? atoi(argv[9]) : 0;            // 1: blocks of two row tiles (64 rows, 4 K slices)
-    const int rfull = ((two ? 64 : 32) / N) * N;
-    const int rpb = rfull > M ? M : rfull, nrb = (M + rpb - 1) / rpb, ncb = n / 64;
+    const int rpb = (32 / N) * N > M ? M : (32 / N) * N, nrb = (M + rpb - 1) / rpb, ncb = n / 64;
     unsigned long long* stamps;
     CK(hipMalloc(&stamps, 64 * 8));
     CK(hipMemset(stamps, 0, 64 * 8));
@@ -107,10 +105,7 @@ int main(int argc, char** argv) {
     printf("M=%d (N=%d x %d scenes) n=%d K=%d gn=%d: %d blocks of 512 threads, forced wait %d\n", M, N, scenes, n, K, gn, nrb * ncb, wait);
     const int ng = K <= 256 ? 1 : K <= 512 ? 2 : K <= 1024 ? 4 : 0;
     const int direct = argc > 8 ? atoi(argv[8]) : 0;         // 1: time the direct-fragment forms even where the staged form applies
-    if (two) {
-        if (gn) run<true, dsc_skinny::STAGED, 2>(sets.data(), R, reps, ncb, rpb, nrb, s, "GN staged, two row tiles");
-        else run<false, dsc_skinny::STAGED, 2>(sets.data(), R, reps, ncb, rpb, nrb, s, "plain staged, two row tiles");
-    } else if ((K % 512) == 0 && !direct) {
+    if ((K % 512) == 0 && !direct) {
         if (gn) run<true, dsc_skinny::STAGED>(sets.data(), R, reps, ncb, rpb, nrb, s, "GN staged");
         else run<false, dsc_skinny::STAGED>(sets.data(), R, reps, ncb, rpb, nrb, s, "plain staged");
     } else if (gn) {
