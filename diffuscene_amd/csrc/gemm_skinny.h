@@ -6,16 +6,16 @@
 // 18 us for a K = 512 launch whatever the (tiny) amount of arithmetic -- 56 GroupNorm launches of 18 us are 58 % of a B = 1 reverse step.
 //
 // This kernel turns the K walk sideways.  A block owns <= 32 token rows (whole scenes) x 64 output channels (exactly one GroupNorm
-// group) and splits K over its EIGHT waves: wave w owns K slice [w K/8, (w+1) K/8) and reads its operand fragments straight from
-// global memory into registers in MFMA lane order -- no LDS staging, no barrier in the product, every load of a K <= 1024 launch in
-// flight at once (longer K: two 32-wide chunks in flight).  The eight partial 32 x 32 tiles meet in LDS, are summed in a fixed order
+// group) and splits K over its EIGHT waves: wave w owns K slice [w K/8, (w+1) K/8) and brings it to the matrix cores on its own -- no
+// block barrier in the product, the loads of a whole K <= 512 slice set in flight at once (two forms of the K section, below: through a
+// wave-private LDS image, or fragments straight from global memory).  The eight partial 32 x 32 tiles meet in LDS, are summed in a fixed order
 // (wave 0..7) by the whole block in ROW layout (thread = token row x 16-byte channel quad), and the epilogue -- bias, activation /
 // GroupNorm + (scale, shift) + SiLU, residual, saved pre-activation -- runs in that layout with fully coalesced global accesses.
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, as gemm_core.h); the K sum is associated as 8 slice sums instead of one
 // chain (error <= the single chain's).  Same C ABI, same argument struct, same epilogue semantics as dsc_gemm::gemm_kernel; the
 // dispatch (gemm_mfma.hip: skinny_plan) takes a launch only when ALL its blocks fit one round of the 256 CUs.
 //
-// Operand fragments without LDS: a lane (l & 31 = row of the 32-row tile, l >> 5 = half) reads 16 bytes = 4 consecutive k at
+// Operand fragments without LDS (forms 1, 2, 4, 0): a lane (l & 31 = row of the 32-row tile, l >> 5 = half) reads 16 bytes = 4 consecutive k at
 // k = base + 8 u + 4 half; MFMA step e of unit u then multiplies element e of both operands' quads -- the two halves supply k = base +
 // 8 u + e and base + 8 u + 4 + e.  A and W use the same rule, so every k of the slice meets its partner exactly once (the ORDER of the k
 // inside a unit differs from the tile kernels'; the set does not).
@@ -57,7 +57,7 @@ constexpr size_t lds_bytes() { return sizeof(float) * (size_t)(NW * wave_lds<NG>
 //     One weight image (32 channels x 64 k) + the token image per wave: the second channel tile overwrites the first once its
 //     fragments are in registers; the partial tiles later reuse the same bytes.
 //   1, 2, 4 -- fragments straight from global memory, the whole slice in NG register buffers of 32 k (K <= 256 NG), every load issued
-//     before the first MFMA; 0 -- the same with two buffers in flight, any K.  (K = 128, 384, 3072 ...)
+//     before the first MFMA; 0 -- the same with two buffers in flight, any K.  (What is left for them: K = 128, 256, 384 ...)
 template <bool GN, int NG>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_args p, int ncolblk, int rows_per_blk) {
     extern __shared__ float smem[];
