@@ -706,7 +706,8 @@ def public_api_line(device):
     build, x_T draw, 1000 reverse steps, post-filter, copy to the host) -- round-5 review items 4 / 5:
       generate_b1_n12 / _n21   network.generate_layout(batch_size=1), the call of scripts/generate_diffusion.py:314-323 (one scene per call),
                                with the default environment (captured hipGraph loop since round 6) and with DSC_GRAPH=0 (eager loop:
-                               ~110 ctypes launches per step from Python); first call (capture) and steady state apart
+                               ~110 ctypes launches per step from Python); first call (capture) and steady state apart; and with the
+                               K-parallel small-launch GEMM off (DSC_SKINNY=0: the tile kernels of rounds 1-5)
       generate_batched_b256    network.generate_layout_batched(batch_size=256) at the metric shape (N = 80)"""
     import torch
     out = {}
@@ -741,8 +742,28 @@ def public_api_line(device):
             os.environ.pop("DSC_GRAPH", None)
             row["DSC_GRAPH=0"] = {"loop": "eager Python loop", "seconds_per_scene": round(te[0], 4), "denoiser_steps_per_s": round(1000.0 / te[0], 1)}
         row["graph_over_eager"] = round(te[0] / ts[1], 2)
+        # the same call with the K-parallel small-launch GEMM (csrc/gemm_skinny.h, round 6) switched off: the tile kernels of rounds 1-5.  A fresh
+        # model: the captured step of the first one has its kernels baked in
+        from diffuscene_amd import _lib
+        lib = _lib.load()
+        prev = lib.dsc_set_skinny(0)
+        try:
+            model0, _ = build_model(spec, device)
+            model0.eval()
+            call0 = lambda: model0.generate_layout(room_mask=room, num_points=N, point_dim=cfg["point_dim"], batch_size=1, text=None,  # noqa: E731
+                                                   device="cpu", clip_denoised=True)
+            with contextlib.redirect_stdout(io.StringIO()):
+                wall(call0, 1)
+                t0s = sorted(wall(call0, 2))
+            row["DSC_SKINNY=0"] = {"loop": "captured hipGraph step, every launch on the tile kernels (K-parallel small-launch GEMM off)",
+                                   "seconds_per_scene": round(t0s[0], 4), "denoiser_steps_per_s": round(1000.0 / t0s[0], 1)}
+            row["k_parallel_gain"] = round(t0s[0] / ts[1], 2)
+            del model0
+        finally:
+            lib.dsc_set_skinny(prev)
         out[name] = row
-        log("public_api: %s default %.3f s / scene (first call %.2f s), eager %.3f s" % (name, ts[1], first, te[0]))
+        log("public_api: %s default %.3f s / scene (first call %.2f s), eager %.3f s, tile kernels only %.3f s"
+            % (name, ts[1], first, te[0], row["DSC_SKINNY=0"]["seconds_per_scene"]))
         del model
         torch.cuda.empty_cache()
     spec = dict(CONFIGS["living80"])
