@@ -75,7 +75,7 @@ int skinny_enabled() {
     return g_skinny;
 }
 
-struct SkinnyPlan { int rows_per_blk, ng, nrb, ncb; };
+struct SkinnyPlan { int rows_per_blk, ng, nrb, ncb; bool r16; };
 
 // Does the K-parallel kernel take this launch?  Shape: K % 64 == 0 (eight slices of whole 8-k units), a K slice inside one operand
 // segment, n % 64 == 0, whole scenes of <= 32 tokens per block, 16-byte aligned rows everywhere, and ALL blocks in one round of the
@@ -95,15 +95,25 @@ bool skinny_plan(const dsc_gemm_args* a, bool gn, SkinnyPlan* out) {
         if (unit > 32) return false;
     }
     const int ncb = a->n / 64;
-    int rpb = (32 / unit) * unit;
-    if (rpb > a->m) rpb = (int)(((int64_t)a->m + unit - 1) / unit * unit);
-    const int64_t nrb = ((int64_t)a->m + rpb - 1) / rpb;
-    if (nrb * ncb * a->batch > 256) return false;
+    // blocks of <= 16 rows (16 x 16 MFMA tiles: half the MFMA time of a padded 32-row tile -- the 12-object scene) where the LDS-staged form
+    // applies and they still fit one round; else blocks of <= 32 rows
+    int rpb = 0;
+    int64_t nrb = 0;
+    bool r16 = false;
+    for (int rows = ((K % 512) == 0 && unit <= 16) ? 16 : 32; rows <= 32 && !rpb; rows += 16) {
+        int r = (rows / unit) * unit;
+        if (r > a->m) r = (int)(((int64_t)a->m + unit - 1) / unit * unit);
+        if (rows == 16 && r > 16) continue;
+        const int64_t nb = ((int64_t)a->m + r - 1) / r;
+        if (nb * ncb * a->batch <= 256) { rpb = r; nrb = nb; r16 = rows == 16; }
+    }
+    if (!rpb) return false;
     auto al = [](const void* q) { return !q || dsc_aligned16(q); };
     if (!al(a->y) || !al(a->residual) || !al(a->bias) || !al(a->preact) || !al(a->gamma) || !al(a->beta) || !al(a->scale_shift)) return false;
     if ((a->ldy & 3) || (a->residual && (a->ldr & 3)) || (a->preact && (a->ld_preact & 3)) || (a->scale_shift && (a->ld_ss & 3))) return false;
     if (a->batch > 1 && ((a->sy & 3) || (a->sres & 3) || (a->sbias & 3))) return false;
     out->rows_per_blk = rpb;
+    out->r16 = r16;
     // K slices of whole 64-k chunks: the LDS-staged form; else fragments straight from global memory (register-resident up to K = 1024)
     out->ng = (K % 512) == 0 ? dsc_skinny::STAGED : K <= 256 ? 1 : K <= 512 ? 2 : K <= 1024 ? 4 : 0;
     out->nrb = (int)nrb;
@@ -111,17 +121,17 @@ bool skinny_plan(const dsc_gemm_args* a, bool gn, SkinnyPlan* out) {
     return true;
 }
 
-template <bool GN, int NG>
+template <bool GN, int NG, bool R16 = false>
 int launch_skinny_ng(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsc_skinny::gemm_skinny_kernel<GN, NG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dsc_skinny::gemm_skinny_kernel<GN, NG, R16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsc_skinny::lds_bytes<NG>());
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     DSC_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL((dsc_skinny::gemm_skinny_kernel<GN, NG>), dim3((unsigned)(sp.nrb * sp.ncb), (unsigned)a->batch),
+    hipLaunchKernelGGL((dsc_skinny::gemm_skinny_kernel<GN, NG, R16>), dim3((unsigned)(sp.nrb * sp.ncb), (unsigned)a->batch),
                        dim3(64 * dsc_skinny::NW), dsc_skinny::lds_bytes<NG>(), s, *a, sp.ncb, sp.rows_per_blk);
     DSC_LAUNCH_CHECK();
     return 0;
@@ -129,6 +139,7 @@ int launch_skinny_ng(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s
 
 template <bool GN>
 int launch_skinny(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s) {
+    if (sp.r16) return launch_skinny_ng<GN, dsc_skinny::STAGED, true>(a, sp, s);
     switch (sp.ng) {
         case 1: return launch_skinny_ng<GN, 1>(a, sp, s);
         case 2: return launch_skinny_ng<GN, 2>(a, sp, s);
@@ -142,11 +153,11 @@ int launch_skinny(const dsc_gemm_args* a, const SkinnyPlan& sp, hipStream_t s) {
 
 extern "C" int dsc_get_skinny(void) { return skinny_enabled(); }
 extern "C" int dsc_set_skinny(int32_t on) { const int prev = skinny_enabled(); g_skinny = on ? 1 : 0; return prev; }
-// 0: a tile kernel (or the split-bf16 family) takes the launch; 1: the K-parallel kernel
+// 0: a tile kernel (or the split-bf16 family) takes the launch; 1: the K-parallel kernel with blocks of <= 32 rows, 2: of <= 16 rows (16 x 16 MFMA tiles)
 extern "C" int dsc_gemm_skinny(const dsc_gemm_args* a, int32_t gn) {
     if (check_common(a) || dsc_gemm_arithmetic(a, gn)) return 0;
     SkinnyPlan sp;
-    return skinny_plan(a, gn != 0, &sp) ? 1 : 0;
+    return skinny_plan(a, gn != 0, &sp) ? (sp.r16 ? 2 : 1) : 0;
 }
 
 // Tile choice: estimated time ~ ceil(blocks / 256 CUs) * tile area (every CU works through its blocks); ties go to the

@@ -5,7 +5,7 @@
 // gemm_core.h make 8..100 blocks that each walk K serially: one global -> LDS -> register round trip per 32-wide K tile, ~1 us each,
 // 18 us for a K = 512 launch whatever the (tiny) amount of arithmetic -- 56 GroupNorm launches of 18 us are 58 % of a B = 1 reverse step.
 //
-// This kernel turns the K walk sideways.  A block owns <= 32 token rows (whole scenes) x 64 output channels (exactly one GroupNorm
+// This kernel turns the K walk sideways.  A block owns <= 32 (or <= 16: R16 below) token rows (whole scenes) x 64 output channels (exactly one GroupNorm
 // group) and splits K over its EIGHT waves: wave w owns K slice [w K/8, (w+1) K/8) and brings it to the matrix cores on its own -- no
 // block barrier in the product, the loads of a whole K <= 512 slice set in flight at once (two forms of the K section, below: through a
 // wave-private LDS image, or fragments straight from global memory).  The eight partial 32 x 32 tiles meet in LDS, are summed in a fixed order
@@ -58,8 +58,13 @@ constexpr size_t lds_bytes() { return sizeof(float) * (size_t)(NW * wave_lds<NG>
 //     fragments are in registers; the partial tiles later reuse the same bytes.
 //   1, 2, 4 -- fragments straight from global memory, the whole slice in NG register buffers of 32 k (K <= 256 NG), every load issued
 //     before the first MFMA; 0 -- the same with two buffers in flight, any K.  (What is left for them: K = 128, 256, 384 ...)
-template <bool GN, int NG>
+//   R16 (staged form only): the block holds <= 16 token rows -- the 12-object bedroom scene of the reference's generation script -- and multiplies
+//     with v_mfma_f32_16x16x4_f32: four 16-channel tiles x ONE 16-token tile per wave, half the MFMA time of the padded 32-row tile.  Lane
+//     (l & 15 = row of the 16-row tile, l >> 4 = k quarter) picks 16 bytes at k = 16 u + 4 (l >> 4) out of the same LDS images; MFMA step e of
+//     unit u multiplies element e of both quads (k = 16 u + 4 q + e for the four quarters q): same rule for both operands.
+template <bool GN, int NG, bool R16 = false>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_args p, int ncolblk, int rows_per_blk) {
+    static_assert(!R16 || NG == STAGED, "16-row blocks: the LDS-staged form only");
     extern __shared__ float smem[];
     DSC_SKINNY_STAMP_DECL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,6 +103,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    f32x4 acc16[4];                              // R16: [16-channel tile]: lane = token l & 15, element r = channel 4 (l >> 4) + r
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc16[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto load = [&](f32x4 (&xa)[UG], f32x4 (&xw)[2][UG], int g) {
 #pragma unroll
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
         f32x4 qa[8], qw[2][8];
         auto gload_a = [&](int ch) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qa[i] = *reinterpret_cast<const f32x4*>(ab + aoff[i] + 64 * ch);
+            for (int i = 0; i < (R16 ? 4 : 8); ++i) qa[i] = *reinterpret_cast<const f32x4*>(ab + aoff[i] + 64 * ch);
         };
         auto gload_w = [&](int ct, int ch) {
 #pragma unroll
@@ -184,6 +192,46 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
         gload_w(1, 0);
         prefetch_epilogue();
         DSC_SKINNY_STAMP_LOADED
+        if constexpr (R16) {
+            const int l15 = lane & 15, kq = lane >> 4;
+            const int f16 = l15 * SLD + 4 * kq;             // fragment read: row l15 of a 16-row tile, k = 16 u + 4 kq
+            auto mma16 = [&](int t0, const f32x4 (&fw)[2][4], const f32x4 (&fa)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2)
+                            acc16[t0 + t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[t2][u][e], fa[u][e], acc16[t0 + t2], 0, 0, 0);
+            };
+            for (int ch = 0; ch < nch; ++ch) {
+                f32x4 fa[4], fw[2][4];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(wimg + 4 * i * SLD + st_off) = qw[0][i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(aimg + 4 * i * SLD + st_off) = qa[i];      // token rows 0..15 only
+                if (ch + 1 < nch) { gload_w(0, ch + 1); gload_a(ch + 1); }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    fa[u] = *reinterpret_cast<const f32x4*>(aimg + f16 + 16 * u);
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) fw[t2][u] = *reinterpret_cast<const f32x4*>(wimg + t2 * 16 * SLD + f16 + 16 * u);
+                }
+                mma16(0, fw, fa);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(wimg + 4 * i * SLD + st_off) = qw[1][i];
+                if (ch + 1 < nch) gload_w(1, ch + 1);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) fw[t2][u] = *reinterpret_cast<const f32x4*>(wimg + t2 * 16 * SLD + f16 + 16 * u);
+                mma16(2, fw, fa);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else
         for (int ch = 0; ch < nch; ++ch) {
             f32x4 fa[8], fw[8];
 #pragma unroll
@@ -242,13 +290,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
 
     DSC_SKINNY_STAMP(1)
     // ---- the eight partial tiles meet in LDS: wave w's bytes, [ct][token][channel]; MFMA layout: lane = token l31, acc[4 q + e] = channel
-    // 8 q + 4 half + e
+    // 8 q + 4 half + e  (R16: [token 16][64 channels], padded rows of SLD floats)
+    if constexpr (R16) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        float* t = wbase + ct * (32 * TLD) + l31 * TLD + 4 * half;
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(wbase + (lane & 15) * SLD + t * 16 + 4 * (lane >> 4)) = acc16[t];
+    } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(t + 8 * q) = f32x4{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+        for (int ct = 0; ct < 2; ++ct) {
+            float* t = wbase + ct * (32 * TLD) + l31 * TLD + 4 * half;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(t + 8 * q) = f32x4{acc[ct][4 * q], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]};
+        }
     }
     __syncthreads();
     DSC_SKINNY_STAMP(2)
@@ -256,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(const dsc_gemm_arg
     // ---- fixed summation order over the waves
     f32x4 v;
     {
-        const float* t = smem + (cq >> 3) * (32 * TLD) + r * TLD + (cq & 7) * 4;
+        const float* t = R16 ? smem + (r & 15) * SLD + cq * 4 : smem + (cq >> 3) * (32 * TLD) + r * TLD + (cq & 7) * 4;
         v = *reinterpret_cast<const f32x4*>(t);
 #pragma unroll
         for (int wv = 1; wv < NW; ++wv) v += *reinterpret_cast<const f32x4*>(t + wv * wave_lds<NG>());

@@ -163,7 +163,7 @@ int dsc_set_split_wave(int32_t mode);
  * the exact-f32 arithmetic when (k1 + k2) % 64 == 0, n % 64 == 0, scenes of <= 32 tokens, 16-byte aligned rows and ALL blocks fit one
  * round of the chip (the one-scene generation call of scripts/generate_diffusion.py:314-323, batches of a few scenes) -- same
  * products, the K sum associated as eight slice sums.  dsc_gemm_skinny: 0 = a tile kernel (or the split family) takes the launch,
- * 1 = this kernel.  Switch: 1 = on (default), 0 = off; initial value from DSC_SKINNY ("0" -> off). */
+ * 1 = this kernel with blocks of <= 32 rows, 2 = with blocks of <= 16 rows (v_mfma_f32_16x16x4_f32 tiles: scenes of <= 16 tokens, K % 512 == 0).  Switch: 1 = on (default), 0 = off; initial value from DSC_SKINNY ("0" -> off). */
 int dsc_gemm_skinny(const dsc_gemm_args* args, int32_t gn);
 int dsc_get_skinny(void);
 int dsc_set_skinny(int32_t on);   /* returns the previous setting */
