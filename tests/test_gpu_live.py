@@ -129,3 +129,30 @@ def test_fifty_step_chain_on_fresh_weights(i, seed):
     r = rel(s, ref)
     print("seed %d: T=50 chain rel err vs live oracle %.3g" % (seed, r))
     assert r < TOL
+
+
+def test_one_scene_chain_on_fresh_weights():
+    """The reference script's call shape -- ONE scene of 12 objects per call (scripts/generate_diffusion.py:314-323) -- whose launches run the
+    K-parallel small-launch GEMM (csrc/gemm_skinny.h, blocks of <= 16 rows): T = 50 chain through the default captured loop against the live oracle."""
+    from diffuscene_amd import _lib, ops
+    from diffuscene_amd.sampler import NoiseReplay
+    seed = 6404
+    kw = dict(W.UNCOND_BEDROOM)
+    sd = W.synth_state_dict(kw, seed=seed)
+    B, N, C = 1, 12, kw["channels"]
+    cond = W.synth_condition(B, N, 128, seed=seed, shared=False)
+    net, diff = _build(kw, sd, time_num=50, model_mean_type="v")
+    # a Block.forward launch of this call shape: the K-parallel kernel with 16 x 16 MFMA tiles takes it (unless switched off)
+    x = torch.zeros(N, 512, device=dev())
+    w, b = torch.zeros(512, 512, device=dev()), torch.zeros(512, device=dev())
+    g = ops.make_gemm_args(x, w, torch.empty(N, 512, device=dev()), b, gamma=b, beta=b, tokens_per_scene=N)
+    assert _lib.fn("dsc_gemm_skinny")(g, 1) == (2 if _lib.load().dsc_get_skinny() else 0)
+    noise_seq = [W.synth_noise((B, N, C), seed, "live_chain_%d" % j) for j in range(51)]
+    tb = R.schedule_tables(1e-4, 0.02, 50, "v")
+    with torch.no_grad():
+        ref = R.p_sample_loop(tb, lambda xt, tt: R.unet1d_forward(sd, kw, xt, tt, cond, None), (B, N, C), noise_seq, 50, clip_denoised=True,
+                              mean_type="v")
+        s = diff.gen_samples((B, N, C), dev(), condition=cond.to(dev()), noise_fn=NoiseReplay(torch.stack(noise_seq).to(dev())), clip_denoised=True)
+    r = rel(s, ref)
+    print("seed %d: B=1 N=12 T=50 chain rel err vs live oracle %.3g" % (seed, r))
+    assert r < TOL
